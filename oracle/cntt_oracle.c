@@ -1,0 +1,1586 @@
+/*
+ * cntt_oracle.c -- CPU ORACLE (TEST INFRASTRUCTURE ONLY, NOT THE PRODUCT).
+ * See cntt_oracle.h for the parity pin.  Every function follows the cited
+ * lines of the scalar (non-SIMD) path of the reference; the reference's own
+ * tests assert that its AVX2/AVX-512 paths produce identical values
+ * (e.g. src/native64.rs:1245-1293, src/prime64.rs:1564-1877).
+ */
+#define _GNU_SOURCE
+#include "cntt_oracle.h"
+
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+typedef orc_u128 u128;
+
+/* ------------------------------------------------------------------------- */
+/* src/lib.rs:118-121  bit_rev: i.reverse_bits() >> (usize::BITS - nbits)      */
+size_t orc_bit_rev(uint32_t nbits, size_t i) {
+    size_t r = 0;
+    for (uint32_t b = 0; b < nbits; ++b) r |= ((i >> b) & 1u) << (nbits - 1 - b);
+    return r;
+}
+
+/* src/fastdiv.rs:157-195 asserts Div32/Div64 equal plain `/` and `%`, so the
+ * native operators are a faithful restatement of the Lemire division. */
+static inline uint32_t mul_mod32(uint32_t p, uint32_t x, uint32_t y) { /* src/prime.rs:4-6 */
+    return (uint32_t)(((uint64_t)x * y) % p);
+}
+uint64_t orc_mul_mod64(uint64_t p, uint64_t x, uint64_t y) { /* src/prime.rs:8-10 */
+    return (uint64_t)(((u128)x * y) % p);
+}
+
+uint32_t orc_exp_mod32(uint32_t p, uint32_t base, uint32_t pow) { /* src/prime.rs:12-29 */
+    if (pow == 0) return 1;
+    uint32_t y = 1, x = base;
+    while (pow > 1) {
+        if (pow % 2 == 1) y = mul_mod32(p, x, y);
+        x = mul_mod32(p, x, x);
+        pow /= 2;
+    }
+    return mul_mod32(p, x, y);
+}
+
+uint64_t orc_exp_mod64(uint64_t p, uint64_t base, uint64_t pow) { /* src/prime.rs:31-48 */
+    if (pow == 0) return 1;
+    uint64_t y = 1, x = base;
+    while (pow > 1) {
+        if (pow % 2 == 1) y = orc_mul_mod64(p, x, y);
+        x = orc_mul_mod64(p, x, x);
+        pow /= 2;
+    }
+    return orc_mul_mod64(p, x, y);
+}
+
+static int miller_rabin_iter(uint64_t n, uint64_t s, uint64_t d, uint64_t a) { /* src/prime.rs:50-66 */
+    uint64_t x = orc_exp_mod64(n, a, d);
+    uint64_t n_minus_1 = n - 1;
+    if (x == 1 || x == n_minus_1) return 1;
+    uint64_t count = 0;
+    while (count < s - 1) {
+        x = orc_mul_mod64(n, x, x);
+        if (x == n_minus_1) return 1;
+        count += 1;
+    }
+    return 0;
+}
+
+int orc_is_prime64(uint64_t n) { /* src/prime.rs:76-126 */
+    if (n < 2) return 0;
+    static const uint64_t small[12] = {2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37};
+    for (int i = 0; i < 12; ++i)
+        if (n % small[i] == 0) return n == small[i];
+    uint64_t s = 0, d = n - 1;
+    while (d % 2 == 0) {
+        s += 1;
+        d /= 2;
+    }
+    for (int i = 0; i < 12; ++i)
+        if (!miller_rabin_iter(n, s, d, small[i])) return 0;
+    return 1;
+}
+
+int orc_largest_prime_in_arithmetic_progression64(uint64_t factor, uint64_t offset, uint64_t lo,
+                                                  uint64_t hi, uint64_t *out) { /* src/prime.rs:130-180 */
+    if (lo > hi) return 0;
+    uint64_t a = factor, b = offset;
+    if (b > hi) return 0;
+    if (a == 0) {
+        if (lo <= b && b <= hi && orc_is_prime64(b)) {
+            *out = b;
+            return 1;
+        }
+        return 0;
+    }
+    uint64_t m = lo > b ? lo : b;
+    uint64_t x_lo = (m - b) / a;
+    if ((m - b) % a != 0) x_lo += 1;
+    uint64_t x_hi = (hi - b) / a;
+    uint64_t x = x_hi;
+    int in_range = 1;
+    while (in_range) {
+        uint64_t val = a * x + b;
+        if (orc_is_prime64(val)) {
+            *out = val;
+            return 1;
+        }
+        if (x == x_lo)
+            in_range = 0;
+        else
+            x -= 1;
+    }
+    return 0;
+}
+
+/* src/roots.rs:6-15 */
+static void get_q_s64(uint64_t p, uint64_t *q, uint64_t *s) {
+    uint64_t qq = p - 1, ss = 0;
+    while (qq % 2 == 0) {
+        qq /= 2;
+        ss += 1;
+    }
+    *q = qq;
+    *s = ss;
+}
+
+int orc_get_z64(uint64_t p, uint64_t *z) { /* src/roots.rs:17-28 */
+    uint64_t n = 2;
+    while (n < p) {
+        if (orc_exp_mod64(p, n, (p - 1) / 2) == p - 1) {
+            *z = n;
+            return 1;
+        }
+        n += 1;
+    }
+    return 0;
+}
+
+int orc_sqrt_mod_ex64(uint64_t p, uint64_t q, uint64_t s, uint64_t z, uint64_t n, uint64_t *out) {
+    /* src/roots.rs:31-66 -- followed literally, no normalisation of the returned root */
+    uint64_t m = s;
+    uint64_t c = orc_exp_mod64(p, z, q);
+    uint64_t t = orc_exp_mod64(p, n, q);
+    uint64_t r = orc_exp_mod64(p, n, (q + 1) / 2);
+    for (;;) {
+        if (t == 0) {
+            *out = 0;
+            return 1;
+        }
+        if (t == 1) {
+            *out = r;
+            return 1;
+        }
+        uint64_t i = 0;
+        uint64_t t_pow = t;
+        while (i < m) {
+            t_pow = orc_mul_mod64(p, t_pow, t_pow);
+            i += 1;
+            if (t_pow == 1) break;
+        }
+        if (i == m) return 0; /* None */
+        uint64_t b = orc_exp_mod64(p, c, (uint64_t)1 << (m - i - 1));
+        m = i;
+        c = orc_mul_mod64(p, b, b);
+        t = orc_mul_mod64(p, t, c);
+        r = orc_mul_mod64(p, r, b);
+    }
+}
+
+int orc_find_primitive_root64(uint64_t p, uint64_t degree, uint64_t *root_out) { /* src/roots.rs:68-91 */
+    /* assert!(degree.is_power_of_two()); assert!(degree > 1); */
+    uint32_t n = (uint32_t)__builtin_ctzll(degree);
+    uint64_t root = p - 1;
+    uint64_t q, s, z;
+    get_q_s64(p, &q, &s);
+    if (!orc_get_z64(p, &z)) return 0;
+    for (uint32_t i = 0; i + 1 < n; ++i) {
+        uint64_t r;
+        if (!orc_sqrt_mod_ex64(p, q, s, z, root, &r)) return 0;
+        root = r;
+    }
+    *root_out = root;
+    return 1;
+}
+
+/* ========================================================================= */
+/* prime64                                                                   */
+/* ========================================================================= */
+#define RECURSION_THRESHOLD64 1024 /* src/prime64.rs:7 */
+#define RECURSION_THRESHOLD32 2048 /* src/prime32.rs:12 */
+#define SOLINAS_P 0xFFFFFFFF00000001ull /* src/prime64/generic_solinas.rs:38-40 */
+
+static inline uint64_t min64(uint64_t a, uint64_t b) { return a < b ? a : b; }
+static inline uint32_t min32(uint32_t a, uint32_t b) { return a < b ? a : b; }
+
+static void *xaligned(size_t bytes) {
+    void *p = NULL;
+    if (bytes == 0) bytes = 64;
+    if (posix_memalign(&p, 64, (bytes + 63) & ~(size_t)63) != 0) return NULL;
+    memset(p, 0, bytes);
+    return p;
+}
+
+/* src/prime64.rs:158-181 (bits < 0: no shoup tables) and :183-218 */
+static void init_negacyclic_twiddles64(uint64_t p, size_t n, int shoup, uint64_t *twid,
+                                       uint64_t *twid_shoup, uint64_t *inv_twid,
+                                       uint64_t *inv_twid_shoup) {
+    uint64_t w = 0;
+    orc_find_primitive_root64(p, 2 * (uint64_t)n, &w);
+    size_t k = 0;
+    uint64_t wk = 1;
+    uint32_t nbits = (uint32_t)__builtin_ctzll(n);
+    while (k < n) {
+        size_t fwd_idx = orc_bit_rev(nbits, k);
+        uint64_t wk_shoup = 0;
+        if (shoup) wk_shoup = (uint64_t)((((u128)wk) << 64) / p);
+        twid[fwd_idx] = wk;
+        if (shoup) twid_shoup[fwd_idx] = wk_shoup;
+        size_t inv_idx = orc_bit_rev(nbits, (n - k) % n);
+        if (k == 0) {
+            inv_twid[inv_idx] = wk;
+            if (shoup) inv_twid_shoup[inv_idx] = wk_shoup;
+        } else {
+            uint64_t x = p - wk;
+            inv_twid[inv_idx] = x;
+            if (shoup) inv_twid_shoup[inv_idx] = (uint64_t)((((u128)x) << 64) / p);
+        }
+        wk = (uint64_t)(((u128)wk * w) % p);
+        k += 1;
+    }
+}
+
+static uint32_t ilog2_64(uint64_t x) { return 63u - (uint32_t)__builtin_clzll(x); }
+
+orc_plan64 *orc_plan64_try_new(size_t n, uint64_t p, int *panicked) { /* src/prime64.rs:704-771 */
+    if (panicked) *panicked = 0;
+    if (p <= 1) { /* Div64::new asserts divisor > 1: src/fastdiv.rs:99 */
+        if (panicked) *panicked = 1;
+        return NULL;
+    }
+    uint64_t root;
+    if (n < 16 || (n & (n - 1)) != 0 || !orc_is_prime64(p) ||
+        !orc_find_primitive_root64(p, 2 * (uint64_t)n, &root))
+        return NULL;
+    /* has_ifma == false: the 52-bit Shoup shift is an internal detail of the IFMA CPU path;
+     * the scalar/AVX2/AVX-512 paths all use bits = 64 (src/prime64.rs:716-725). */
+    const uint32_t bits = 64;
+    orc_plan64 *plan = (orc_plan64 *)calloc(1, sizeof(*plan));
+    plan->n = n;
+    plan->p = p;
+    plan->twid = (uint64_t *)xaligned(n * 8);
+    plan->inv_twid = (uint64_t *)xaligned(n * 8);
+    int shoup = p < ((uint64_t)1 << 63);
+    if (shoup) {
+        plan->twid_shoup = (uint64_t *)xaligned(n * 8);
+        plan->inv_twid_shoup = (uint64_t *)xaligned(n * 8);
+    }
+    init_negacyclic_twiddles64(p, n, shoup, plan->twid, plan->twid_shoup, plan->inv_twid,
+                               plan->inv_twid_shoup);
+    plan->n_inv_mod_p = orc_exp_mod64(p, (uint64_t)n, p - 2);
+    plan->n_inv_mod_p_shoup = (uint64_t)((((u128)plan->n_inv_mod_p) << bits) / p);
+    plan->big_q = ilog2_64(p) + 1;
+    uint64_t big_l = plan->big_q + (bits - 1);
+    /* (1u128 << big_l) / p as u64; for p >= 2^63 big_l = 127 and the value is unused */
+    plan->p_barrett = (uint64_t)((((u128)1) << big_l) / p);
+    return plan;
+}
+
+void orc_plan64_free(orc_plan64 *plan) {
+    if (!plan) return;
+    free(plan->twid);
+    free(plan->twid_shoup);
+    free(plan->inv_twid);
+    free(plan->inv_twid_shoup);
+    free(plan);
+}
+
+/* ---- butterflies.  class 62: src/prime64/less_than_62bit.rs:117-154, :271-310
+ *                    class 63: src/prime64/less_than_63bit.rs:117-154, :214-232 ---- */
+typedef struct {
+    uint64_t a, b;
+} pair64;
+
+static inline pair64 fwd_bfly62(uint64_t z0, uint64_t z1, uint64_t w, uint64_t ws, uint64_t p,
+                                uint64_t neg_p, uint64_t two_p) {
+    (void)p;
+    z0 = min64(z0, z0 - two_p);
+    uint64_t shoup_q = (uint64_t)(((u128)z1 * ws) >> 64);
+    uint64_t t = z1 * w + shoup_q * neg_p;
+    return (pair64){z0 + t, z0 - t + two_p};
+}
+static inline pair64 fwd_last_bfly62(uint64_t z0, uint64_t z1, uint64_t w, uint64_t ws, uint64_t p,
+                                     uint64_t neg_p, uint64_t two_p) {
+    z0 = min64(z0, z0 - two_p);
+    z0 = min64(z0, z0 - p);
+    uint64_t shoup_q = (uint64_t)(((u128)z1 * ws) >> 64);
+    uint64_t t = z1 * w + shoup_q * neg_p;
+    t = min64(t, t - p);
+    uint64_t r0 = z0 + t, r1 = z0 - t + p;
+    return (pair64){min64(r0, r0 - p), min64(r1, r1 - p)};
+}
+static inline pair64 inv_bfly62(uint64_t z0, uint64_t z1, uint64_t w, uint64_t ws, uint64_t p,
+                                uint64_t neg_p, uint64_t two_p) {
+    (void)p;
+    uint64_t y0 = z0 + z1;
+    y0 = min64(y0, y0 - two_p);
+    uint64_t t = z0 - z1 + two_p;
+    uint64_t shoup_q = (uint64_t)(((u128)t * ws) >> 64);
+    uint64_t y1 = t * w + shoup_q * neg_p;
+    return (pair64){y0, y1};
+}
+static inline pair64 inv_last_bfly62(uint64_t z0, uint64_t z1, uint64_t w, uint64_t ws, uint64_t p,
+                                     uint64_t neg_p, uint64_t two_p) {
+    uint64_t y0 = z0 + z1;
+    y0 = min64(y0, y0 - two_p);
+    y0 = min64(y0, y0 - p);
+    uint64_t t = z0 - z1 + two_p;
+    uint64_t shoup_q = (uint64_t)(((u128)t * ws) >> 64);
+    uint64_t y1 = t * w + shoup_q * neg_p;
+    y1 = min64(y1, y1 - p);
+    return (pair64){y0, y1};
+}
+static inline pair64 fwd_bfly63(uint64_t z0, uint64_t z1, uint64_t w, uint64_t ws, uint64_t p,
+                                uint64_t neg_p, uint64_t two_p) {
+    (void)two_p;
+    z0 = min64(z0, z0 - p);
+    uint64_t shoup_q = (uint64_t)(((u128)z1 * ws) >> 64);
+    uint64_t t = z1 * w + shoup_q * neg_p;
+    t = min64(t, t - p);
+    return (pair64){z0 + t, z0 - t + p};
+}
+static inline pair64 fwd_last_bfly63(uint64_t z0, uint64_t z1, uint64_t w, uint64_t ws, uint64_t p,
+                                     uint64_t neg_p, uint64_t two_p) {
+    (void)two_p;
+    z0 = min64(z0, z0 - p);
+    uint64_t shoup_q = (uint64_t)(((u128)z1 * ws) >> 64);
+    uint64_t t = z1 * w + shoup_q * neg_p;
+    t = min64(t, t - p);
+    uint64_t r0 = z0 + t, r1 = z0 - t + p;
+    return (pair64){min64(r0, r0 - p), min64(r1, r1 - p)};
+}
+static inline pair64 inv_bfly63(uint64_t z0, uint64_t z1, uint64_t w, uint64_t ws, uint64_t p,
+                                uint64_t neg_p, uint64_t two_p) {
+    (void)two_p;
+    uint64_t y0 = z0 + z1;
+    y0 = min64(y0, y0 - p);
+    uint64_t t = z0 - z1 + p;
+    uint64_t shoup_q = (uint64_t)(((u128)t * ws) >> 64);
+    uint64_t y1 = t * w + shoup_q * neg_p;
+    y1 = min64(y1, y1 - p);
+    return (pair64){y0, y1};
+}
+
+typedef pair64 (*bfly64_fn)(uint64_t, uint64_t, uint64_t, uint64_t, uint64_t, uint64_t, uint64_t);
+
+/* src/prime64/shoup.rs:544-615 */
+static void fwd_breadth_first_scalar64(uint64_t p, uint64_t *data, size_t n, const uint64_t *twid,
+                                       const uint64_t *twid_shoup, size_t depth, size_t half,
+                                       bfly64_fn butterfly, bfly64_fn last_butterfly) {
+    size_t t = n, m = 1;
+    size_t w_idx = (m << depth) + half * m;
+    uint64_t neg_p = (uint64_t)0 - p, two_p = 2 * p;
+    while (m < n) {
+        t /= 2;
+        const uint64_t *w = twid + w_idx, *ws = twid_shoup + w_idx;
+        bfly64_fn f = (t == 1) ? last_butterfly : butterfly;
+        for (size_t blk = 0; blk < n / (2 * t); ++blk) {
+            uint64_t *z0 = data + blk * 2 * t, *z1 = z0 + t;
+            for (size_t j = 0; j < t; ++j) {
+                pair64 r = f(z0[j], z1[j], w[blk], ws[blk], p, neg_p, two_p);
+                z0[j] = r.a;
+                z1[j] = r.b;
+            }
+        }
+        m *= 2;
+        w_idx *= 2;
+    }
+}
+
+/* src/prime64/shoup.rs:617-706 */
+static void fwd_depth_first_scalar64(uint64_t p, uint64_t *data, size_t n, const uint64_t *twid,
+                                     const uint64_t *twid_shoup, size_t depth, size_t half,
+                                     bfly64_fn butterfly, bfly64_fn last_butterfly) {
+    if (n <= RECURSION_THRESHOLD64) {
+        fwd_breadth_first_scalar64(p, data, n, twid, twid_shoup, depth, half, butterfly, last_butterfly);
+        return;
+    }
+    size_t t = n / 2, m = 1;
+    size_t w_idx = (m << depth) + m * half;
+    uint64_t neg_p = (uint64_t)0 - p, two_p = 2 * p;
+    uint64_t w = twid[w_idx], ws = twid_shoup[w_idx];
+    for (size_t j = 0; j < t; ++j) {
+        pair64 r = butterfly(data[j], data[t + j], w, ws, p, neg_p, two_p);
+        data[j] = r.a;
+        data[t + j] = r.b;
+    }
+    fwd_depth_first_scalar64(p, data, n / 2, twid, twid_shoup, depth + 1, half * 2, butterfly, last_butterfly);
+    fwd_depth_first_scalar64(p, data + n / 2, n / 2, twid, twid_shoup, depth + 1, half * 2 + 1, butterfly,
+                             last_butterfly);
+}
+
+/* src/prime64/shoup.rs:1306-1377 */
+static void inv_breadth_first_scalar64(uint64_t p, uint64_t *data, size_t n, const uint64_t *inv_twid,
+                                       const uint64_t *inv_twid_shoup, size_t depth, size_t half,
+                                       bfly64_fn butterfly, bfly64_fn last_butterfly) {
+    size_t t = 1, m = n;
+    size_t w_idx = (m << depth) + half * m;
+    uint64_t neg_p = (uint64_t)0 - p, two_p = 2 * p;
+    while (m > 1) {
+        m /= 2;
+        w_idx /= 2;
+        const uint64_t *w = inv_twid + w_idx, *ws = inv_twid_shoup + w_idx;
+        bfly64_fn f = (m == 1) ? last_butterfly : butterfly;
+        for (size_t blk = 0; blk < n / (2 * t); ++blk) {
+            uint64_t *z0 = data + blk * 2 * t, *z1 = z0 + t;
+            for (size_t j = 0; j < t; ++j) {
+                pair64 r = f(z0[j], z1[j], w[blk], ws[blk], p, neg_p, two_p);
+                z0[j] = r.a;
+                z1[j] = r.b;
+            }
+        }
+        t *= 2;
+    }
+}
+
+/* src/prime64/shoup.rs:1379-1468 */
+static void inv_depth_first_scalar64(uint64_t p, uint64_t *data, size_t n, const uint64_t *inv_twid,
+                                     const uint64_t *inv_twid_shoup, size_t depth, size_t half,
+                                     bfly64_fn butterfly, bfly64_fn last_butterfly) {
+    if (n <= RECURSION_THRESHOLD64) {
+        inv_breadth_first_scalar64(p, data, n, inv_twid, inv_twid_shoup, depth, half, butterfly, last_butterfly);
+        return;
+    }
+    inv_depth_first_scalar64(p, data, n / 2, inv_twid, inv_twid_shoup, depth + 1, half * 2, butterfly, butterfly);
+    inv_depth_first_scalar64(p, data + n / 2, n / 2, inv_twid, inv_twid_shoup, depth + 1, half * 2 + 1,
+                             butterfly, butterfly);
+    size_t t = n / 2, m = 1;
+    size_t w_idx = (m << depth) + m * half;
+    uint64_t neg_p = (uint64_t)0 - p, two_p = 2 * p;
+    uint64_t w = inv_twid[w_idx], ws = inv_twid_shoup[w_idx];
+    for (size_t j = 0; j < t; ++j) {
+        pair64 r = last_butterfly(data[j], data[t + j], w, ws, p, neg_p, two_p);
+        data[j] = r.a;
+        data[t + j] = r.b;
+    }
+}
+
+/* ---- generic / Solinas (src/prime64/generic_solinas.rs) ---- */
+static inline uint64_t gen_add64(uint64_t p, uint64_t a, uint64_t b) { /* :46-58 / :80-89 */
+    uint64_t neg_b = p - b;
+    return (a >= neg_b) ? a - neg_b : a + b;
+}
+static inline uint64_t gen_sub64(uint64_t p, uint64_t a, uint64_t b) { /* :60-69 / :91-100 */
+    uint64_t neg_b = p - b;
+    return (a >= b) ? a - b : a + neg_b;
+}
+static inline uint64_t solinas_mul(uint64_t a, uint64_t b) { /* :102-128 */
+    const uint64_t p = SOLINAS_P;
+    u128 wide = (u128)a * b;
+    uint64_t lo = (uint64_t)wide;
+    uint64_t hi = (uint64_t)(wide >> 64);
+    uint64_t mid = hi & 0x00000000FFFFFFFFull;
+    hi = (hi & 0xFFFFFFFF00000000ull) >> 32;
+    uint64_t low2 = lo - hi;
+    if (hi > lo) low2 += p;
+    uint64_t product = mid << 32;
+    product -= mid;
+    uint64_t result = low2 + product;
+    if ((result < product) || (result >= p)) result -= p;
+    return result;
+}
+static inline uint64_t gen_mul64(uint64_t p, int solinas, uint64_t a, uint64_t b) {
+    return solinas ? solinas_mul(a, b) : (uint64_t)(((u128)a * b) % p); /* :71-75 */
+}
+
+/* :449-481 */
+static void gen_fwd_breadth_first64(uint64_t *data, size_t n, uint64_t p, int solinas, const uint64_t *twid,
+                                    size_t depth, size_t half) {
+    size_t t = n / 2, m = 1;
+    size_t w_idx = (m << depth) + half * m;
+    while (m < n) {
+        const uint64_t *w = twid + w_idx;
+        for (size_t blk = 0; blk < n / (2 * t); ++blk) {
+            uint64_t *z0 = data + blk * 2 * t, *z1 = z0 + t;
+            uint64_t w1 = w[blk];
+            for (size_t j = 0; j < t; ++j) {
+                uint64_t z1w = gen_mul64(p, solinas, z1[j], w1);
+                uint64_t a = gen_add64(p, z0[j], z1w), b = gen_sub64(p, z0[j], z1w);
+                z0[j] = a;
+                z1[j] = b;
+            }
+        }
+        t /= 2;
+        m *= 2;
+        w_idx *= 2;
+    }
+}
+/* :1338-1386 */
+static void gen_fwd_depth_first64(uint64_t *data, size_t n, uint64_t p, int solinas, const uint64_t *twid,
+                                  size_t depth, size_t half) {
+    if (n <= RECURSION_THRESHOLD64) {
+        gen_fwd_breadth_first64(data, n, p, solinas, twid, depth, half);
+        return;
+    }
+    size_t t = n / 2, m = 1;
+    size_t w_idx = (m << depth) + m * half;
+    uint64_t w1 = twid[w_idx];
+    for (size_t j = 0; j < t; ++j) {
+        uint64_t z1w = gen_mul64(p, solinas, data[t + j], w1);
+        uint64_t a = gen_add64(p, data[j], z1w), b = gen_sub64(p, data[j], z1w);
+        data[j] = a;
+        data[t + j] = b;
+    }
+    gen_fwd_depth_first64(data, n / 2, p, solinas, twid, depth + 1, half * 2);
+    gen_fwd_depth_first64(data + n / 2, n / 2, p, solinas, twid, depth + 1, half * 2 + 1);
+}
+/* :483-513 */
+static void gen_inv_breadth_first64(uint64_t *data, size_t n, uint64_t p, int solinas,
+                                    const uint64_t *inv_twid, size_t depth, size_t half) {
+    size_t t = 1, m = n;
+    size_t w_idx = (m << depth) + half * m;
+    while (m > 1) {
+        m /= 2;
+        w_idx /= 2;
+        const uint64_t *w = inv_twid + w_idx;
+        for (size_t blk = 0; blk < n / (2 * t); ++blk) {
+            uint64_t *z0 = data + blk * 2 * t, *z1 = z0 + t;
+            uint64_t w1 = w[blk];
+            for (size_t j = 0; j < t; ++j) {
+                uint64_t a = gen_add64(p, z0[j], z1[j]);
+                uint64_t b = gen_mul64(p, solinas, gen_sub64(p, z0[j], z1[j]), w1);
+                z0[j] = a;
+                z1[j] = b;
+            }
+        }
+        t *= 2;
+    }
+}
+/* :515-561 */
+static void gen_inv_depth_first64(uint64_t *data, size_t n, uint64_t p, int solinas, const uint64_t *inv_twid,
+                                  size_t depth, size_t half) {
+    if (n <= RECURSION_THRESHOLD64) {
+        gen_inv_breadth_first64(data, n, p, solinas, inv_twid, depth, half);
+        return;
+    }
+    gen_inv_depth_first64(data, n / 2, p, solinas, inv_twid, depth + 1, half * 2);
+    gen_inv_depth_first64(data + n / 2, n / 2, p, solinas, inv_twid, depth + 1, half * 2 + 1);
+    size_t t = n / 2, m = 1;
+    size_t w_idx = (m << depth) + m * half;
+    uint64_t w1 = inv_twid[w_idx];
+    for (size_t j = 0; j < t; ++j) {
+        uint64_t a = gen_add64(p, data[j], data[t + j]);
+        uint64_t b = gen_mul64(p, solinas, gen_sub64(p, data[j], data[t + j]), w1);
+        data[j] = a;
+        data[t + j] = b;
+    }
+}
+
+void orc_plan64_fwd(const orc_plan64 *plan, uint64_t *buf) { /* src/prime64.rs:794-865 */
+    uint64_t p = plan->p;
+    size_t n = plan->n;
+    if (p < ((uint64_t)1 << 62))
+        fwd_depth_first_scalar64(p, buf, n, plan->twid, plan->twid_shoup, 0, 0, fwd_bfly62, fwd_last_bfly62);
+    else if (p < ((uint64_t)1 << 63))
+        fwd_depth_first_scalar64(p, buf, n, plan->twid, plan->twid_shoup, 0, 0, fwd_bfly63, fwd_last_bfly63);
+    else
+        gen_fwd_depth_first64(buf, n, p, p == SOLINAS_P, plan->twid, 0, 0);
+}
+
+void orc_plan64_inv(const orc_plan64 *plan, uint64_t *buf) { /* src/prime64.rs:872-943 */
+    uint64_t p = plan->p;
+    size_t n = plan->n;
+    if (p < ((uint64_t)1 << 62))
+        inv_depth_first_scalar64(p, buf, n, plan->inv_twid, plan->inv_twid_shoup, 0, 0, inv_bfly62,
+                                 inv_last_bfly62);
+    else if (p < ((uint64_t)1 << 63)) /* 63-bit class has no separate last butterfly: less_than_63bit.rs */
+        inv_depth_first_scalar64(p, buf, n, plan->inv_twid, plan->inv_twid_shoup, 0, 0, inv_bfly63, inv_bfly63);
+    else
+        gen_inv_depth_first64(buf, n, p, p == SOLINAS_P, plan->inv_twid, 0, 0);
+}
+
+void orc_plan64_mul_assign_normalize(const orc_plan64 *plan, uint64_t *lhs, const uint64_t *rhs, size_t len) {
+    uint64_t p = plan->p;
+    if (p < ((uint64_t)1 << 63)) { /* src/prime64.rs:534-559 */
+        uint64_t big_q_m1 = plan->big_q - 1;
+        for (size_t i = 0; i < len; ++i) {
+            u128 d = (u128)lhs[i] * rhs[i];
+            uint64_t c1 = (uint64_t)(d >> big_q_m1);
+            uint64_t c3 = (uint64_t)(((u128)c1 * plan->p_barrett) >> 64);
+            uint64_t prod = (uint64_t)d - p * c3;
+            uint64_t shoup_q = (uint64_t)(((u128)prod * plan->n_inv_mod_p_shoup) >> 64);
+            uint64_t t = prod * plan->n_inv_mod_p - shoup_q * p;
+            lhs[i] = min64(t, t - p);
+        }
+    } else { /* :1013-1032 */
+        int solinas = p == SOLINAS_P;
+        for (size_t i = 0; i < len; ++i) {
+            uint64_t prod = gen_mul64(p, solinas, lhs[i], rhs[i]);
+            lhs[i] = gen_mul64(p, solinas, prod, plan->n_inv_mod_p);
+        }
+    }
+}
+
+void orc_plan64_normalize(const orc_plan64 *plan, uint64_t *values, size_t len) {
+    uint64_t p = plan->p;
+    if (p < ((uint64_t)1 << 63)) { /* src/prime64.rs:690-699 */
+        for (size_t i = 0; i < len; ++i) {
+            uint64_t val = values[i];
+            uint64_t shoup_q = (uint64_t)(((u128)val * plan->n_inv_mod_p_shoup) >> 64);
+            uint64_t t = val * plan->n_inv_mod_p - shoup_q * p;
+            values[i] = min64(t, t - p);
+        }
+    } else { /* :1068-1081 */
+        int solinas = p == SOLINAS_P;
+        for (size_t i = 0; i < len; ++i) values[i] = gen_mul64(p, solinas, values[i], plan->n_inv_mod_p);
+    }
+}
+
+void orc_plan64_mul_accumulate(const orc_plan64 *plan, uint64_t *acc, const uint64_t *lhs, const uint64_t *rhs,
+                               size_t len) {
+    uint64_t p = plan->p;
+    if (p < ((uint64_t)1 << 63)) { /* src/prime64.rs:561-584 */
+        uint64_t big_q_m1 = plan->big_q - 1;
+        for (size_t i = 0; i < len; ++i) {
+            u128 d = (u128)lhs[i] * rhs[i];
+            uint64_t c1 = (uint64_t)(d >> big_q_m1);
+            uint64_t c3 = (uint64_t)(((u128)c1 * plan->p_barrett) >> 64);
+            uint64_t prod = (uint64_t)d - p * c3;
+            prod = min64(prod, prod - p);
+            uint64_t acc_ = prod + acc[i];
+            acc[i] = min64(acc_, acc_ - p);
+        }
+    } else { /* :1116-1127 */
+        int solinas = p == SOLINAS_P;
+        for (size_t i = 0; i < len; ++i) {
+            uint64_t prod = gen_mul64(p, solinas, lhs[i], rhs[i]);
+            acc[i] = gen_add64(p, acc[i], prod);
+        }
+    }
+}
+
+/* ========================================================================= */
+/* prime32                                                                   */
+/* ========================================================================= */
+/* src/prime32.rs:223-282 */
+static void init_negacyclic_twiddles32(uint32_t p, size_t n, int shoup, uint32_t *twid, uint32_t *twid_shoup,
+                                       uint32_t *inv_twid, uint32_t *inv_twid_shoup) {
+    uint64_t w64 = 0;
+    orc_find_primitive_root64((uint64_t)p, 2 * (uint64_t)n, &w64);
+    uint32_t w = (uint32_t)w64;
+    size_t k = 0;
+    uint32_t wk = 1;
+    uint32_t nbits = (uint32_t)__builtin_ctzll(n);
+    while (k < n) {
+        size_t fwd_idx = orc_bit_rev(nbits, k);
+        uint32_t wk_shoup = 0;
+        if (shoup) wk_shoup = (uint32_t)((((uint64_t)wk) << 32) / p);
+        twid[fwd_idx] = wk;
+        if (shoup) twid_shoup[fwd_idx] = wk_shoup;
+        size_t inv_idx = orc_bit_rev(nbits, (n - k) % n);
+        if (k == 0) {
+            inv_twid[inv_idx] = wk;
+            if (shoup) inv_twid_shoup[inv_idx] = wk_shoup;
+        } else {
+            uint32_t x = p - wk;
+            inv_twid[inv_idx] = x;
+            if (shoup) inv_twid_shoup[inv_idx] = (uint32_t)((((uint64_t)x) << 32) / p);
+        }
+        wk = (uint32_t)(((uint64_t)wk * w) % p);
+        k += 1;
+    }
+}
+
+orc_plan32 *orc_plan32_try_new(size_t n, uint32_t p, int *panicked) { /* src/prime32.rs:630-686 */
+    if (panicked) *panicked = 0;
+    if (p <= 1) { /* Div32::new asserts divisor > 1: src/fastdiv.rs:48-49 */
+        if (panicked) *panicked = 1;
+        return NULL;
+    }
+    uint64_t root;
+    if (n < 32 || (n & (n - 1)) != 0 || !orc_is_prime64((uint64_t)p) ||
+        !orc_find_primitive_root64((uint64_t)p, 2 * (uint64_t)n, &root))
+        return NULL;
+    orc_plan32 *plan = (orc_plan32 *)calloc(1, sizeof(*plan));
+    plan->n = n;
+    plan->p = p;
+    plan->twid = (uint32_t *)xaligned(n * 4);
+    plan->inv_twid = (uint32_t *)xaligned(n * 4);
+    int shoup = p < ((uint32_t)1 << 31);
+    if (shoup) {
+        plan->twid_shoup = (uint32_t *)xaligned(n * 4);
+        plan->inv_twid_shoup = (uint32_t *)xaligned(n * 4);
+    }
+    init_negacyclic_twiddles32(p, n, shoup, plan->twid, plan->twid_shoup, plan->inv_twid, plan->inv_twid_shoup);
+    plan->n_inv_mod_p = orc_exp_mod32(p, (uint32_t)n, p - 2);
+    plan->n_inv_mod_p_shoup = (uint32_t)((((uint64_t)plan->n_inv_mod_p) << 32) / p);
+    plan->big_q = (31u - (uint32_t)__builtin_clz(p)) + 1;
+    uint32_t big_l = plan->big_q + 31;
+    plan->p_barrett = (uint32_t)((((uint64_t)1) << big_l) / p);
+    return plan;
+}
+
+void orc_plan32_free(orc_plan32 *plan) {
+    if (!plan) return;
+    free(plan->twid);
+    free(plan->twid_shoup);
+    free(plan->inv_twid);
+    free(plan->inv_twid_shoup);
+    free(plan);
+}
+
+typedef struct {
+    uint32_t a, b;
+} pair32;
+typedef pair32 (*bfly32_fn)(uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t);
+
+/* src/prime32/less_than_30bit.rs:115-153, :265-303 */
+static inline pair32 fwd_bfly30(uint32_t z0, uint32_t z1, uint32_t w, uint32_t ws, uint32_t p, uint32_t neg_p,
+                                uint32_t two_p) {
+    (void)p;
+    z0 = min32(z0, z0 - two_p);
+    uint32_t shoup_q = (uint32_t)(((uint64_t)z1 * ws) >> 32);
+    uint32_t t = z1 * w + shoup_q * neg_p;
+    return (pair32){z0 + t, z0 - t + two_p};
+}
+static inline pair32 fwd_last_bfly30(uint32_t z0, uint32_t z1, uint32_t w, uint32_t ws, uint32_t p,
+                                     uint32_t neg_p, uint32_t two_p) {
+    z0 = min32(z0, z0 - two_p);
+    z0 = min32(z0, z0 - p);
+    uint32_t shoup_q = (uint32_t)(((uint64_t)z1 * ws) >> 32);
+    uint32_t t = z1 * w + shoup_q * neg_p;
+    t = min32(t, t - p);
+    uint32_t r0 = z0 + t, r1 = z0 - t + p;
+    return (pair32){min32(r0, r0 - p), min32(r1, r1 - p)};
+}
+static inline pair32 inv_bfly30(uint32_t z0, uint32_t z1, uint32_t w, uint32_t ws, uint32_t p, uint32_t neg_p,
+                                uint32_t two_p) {
+    (void)p;
+    uint32_t y0 = z0 + z1;
+    y0 = min32(y0, y0 - two_p);
+    uint32_t t = z0 - z1 + two_p;
+    uint32_t shoup_q = (uint32_t)(((uint64_t)t * ws) >> 32);
+    uint32_t y1 = t * w + shoup_q * neg_p;
+    return (pair32){y0, y1};
+}
+static inline pair32 inv_last_bfly30(uint32_t z0, uint32_t z1, uint32_t w, uint32_t ws, uint32_t p,
+                                     uint32_t neg_p, uint32_t two_p) {
+    uint32_t y0 = z0 + z1;
+    y0 = min32(y0, y0 - two_p);
+    uint32_t t = z0 - z1 + two_p;
+    uint32_t shoup_q = (uint32_t)(((uint64_t)t * ws) >> 32);
+    uint32_t y1 = t * w + shoup_q * neg_p;
+    return (pair32){min32(y0, y0 - p), min32(y1, y1 - p)};
+}
+/* src/prime32/less_than_31bit.rs:117-156, :214-233 */
+static inline pair32 fwd_bfly31(uint32_t z0, uint32_t z1, uint32_t w, uint32_t ws, uint32_t p, uint32_t neg_p,
+                                uint32_t two_p) {
+    (void)two_p;
+    z0 = min32(z0, z0 - p);
+    uint32_t shoup_q = (uint32_t)(((uint64_t)z1 * ws) >> 32);
+    uint32_t t = z1 * w + shoup_q * neg_p;
+    t = min32(t, t - p);
+    return (pair32){z0 + t, z0 - t + p};
+}
+static inline pair32 fwd_last_bfly31(uint32_t z0, uint32_t z1, uint32_t w, uint32_t ws, uint32_t p,
+                                     uint32_t neg_p, uint32_t two_p) {
+    (void)two_p;
+    z0 = min32(z0, z0 - p);
+    uint32_t shoup_q = (uint32_t)(((uint64_t)z1 * ws) >> 32);
+    uint32_t t = z1 * w + shoup_q * neg_p;
+    t = min32(t, t - p);
+    uint32_t r0 = z0 + t, r1 = z0 - t + p;
+    return (pair32){min32(r0, r0 - p), min32(r1, r1 - p)};
+}
+static inline pair32 inv_bfly31(uint32_t z0, uint32_t z1, uint32_t w, uint32_t ws, uint32_t p, uint32_t neg_p,
+                                uint32_t two_p) {
+    (void)two_p;
+    uint32_t y0 = z0 + z1;
+    y0 = min32(y0, y0 - p);
+    uint32_t t = z0 - z1 + p;
+    uint32_t shoup_q = (uint32_t)(((uint64_t)t * ws) >> 32);
+    uint32_t y1 = t * w + shoup_q * neg_p;
+    y1 = min32(y1, y1 - p);
+    return (pair32){y0, y1};
+}
+
+/* src/prime32/shoup.rs:582-635 */
+static void fwd_breadth_first_scalar32(uint32_t p, uint32_t *data, size_t n, const uint32_t *twid,
+                                       const uint32_t *twid_shoup, size_t depth, size_t half,
+                                       bfly32_fn butterfly, bfly32_fn last_butterfly) {
+    size_t t = n, m = 1;
+    size_t w_idx = (m << depth) + half * m;
+    uint32_t neg_p = (uint32_t)0 - p, two_p = 2 * p;
+    while (m < n) {
+        t /= 2;
+        const uint32_t *w = twid + w_idx, *ws = twid_shoup + w_idx;
+        bfly32_fn f = (t == 1) ? last_butterfly : butterfly;
+        for (size_t blk = 0; blk < n / (2 * t); ++blk) {
+            uint32_t *z0 = data + blk * 2 * t, *z1 = z0 + t;
+            for (size_t j = 0; j < t; ++j) {
+                pair32 r = f(z0[j], z1[j], w[blk], ws[blk], p, neg_p, two_p);
+                z0[j] = r.a;
+                z1[j] = r.b;
+            }
+        }
+        m *= 2;
+        w_idx *= 2;
+    }
+}
+/* src/prime32/shoup.rs:637-708 */
+static void fwd_depth_first_scalar32(uint32_t p, uint32_t *data, size_t n, const uint32_t *twid,
+                                     const uint32_t *twid_shoup, size_t depth, size_t half,
+                                     bfly32_fn butterfly, bfly32_fn last_butterfly) {
+    if (n <= RECURSION_THRESHOLD32) {
+        fwd_breadth_first_scalar32(p, data, n, twid, twid_shoup, depth, half, butterfly, last_butterfly);
+        return;
+    }
+    size_t t = n / 2, m = 1;
+    size_t w_idx = (m << depth) + m * half;
+    uint32_t neg_p = (uint32_t)0 - p, two_p = 2 * p;
+    uint32_t w = twid[w_idx], ws = twid_shoup[w_idx];
+    for (size_t j = 0; j < t; ++j) {
+        pair32 r = butterfly(data[j], data[t + j], w, ws, p, neg_p, two_p);
+        data[j] = r.a;
+        data[t + j] = r.b;
+    }
+    fwd_depth_first_scalar32(p, data, n / 2, twid, twid_shoup, depth + 1, half * 2, butterfly, last_butterfly);
+    fwd_depth_first_scalar32(p, data + n / 2, n / 2, twid, twid_shoup, depth + 1, half * 2 + 1, butterfly,
+                             last_butterfly);
+}
+/* src/prime32/shoup.rs:1355-1408 */
+static void inv_breadth_first_scalar32(uint32_t p, uint32_t *data, size_t n, const uint32_t *inv_twid,
+                                       const uint32_t *inv_twid_shoup, size_t depth, size_t half,
+                                       bfly32_fn butterfly, bfly32_fn last_butterfly) {
+    size_t t = 1, m = n;
+    size_t w_idx = (m << depth) + half * m;
+    uint32_t neg_p = (uint32_t)0 - p, two_p = 2 * p;
+    while (m > 1) {
+        m /= 2;
+        w_idx /= 2;
+        const uint32_t *w = inv_twid + w_idx, *ws = inv_twid_shoup + w_idx;
+        bfly32_fn f = (m == 1) ? last_butterfly : butterfly;
+        for (size_t blk = 0; blk < n / (2 * t); ++blk) {
+            uint32_t *z0 = data + blk * 2 * t, *z1 = z0 + t;
+            for (size_t j = 0; j < t; ++j) {
+                pair32 r = f(z0[j], z1[j], w[blk], ws[blk], p, neg_p, two_p);
+                z0[j] = r.a;
+                z1[j] = r.b;
+            }
+        }
+        t *= 2;
+    }
+}
+/* src/prime32/shoup.rs:1410-1481 */
+static void inv_depth_first_scalar32(uint32_t p, uint32_t *data, size_t n, const uint32_t *inv_twid,
+                                     const uint32_t *inv_twid_shoup, size_t depth, size_t half,
+                                     bfly32_fn butterfly, bfly32_fn last_butterfly) {
+    if (n <= RECURSION_THRESHOLD32) {
+        inv_breadth_first_scalar32(p, data, n, inv_twid, inv_twid_shoup, depth, half, butterfly, last_butterfly);
+        return;
+    }
+    inv_depth_first_scalar32(p, data, n / 2, inv_twid, inv_twid_shoup, depth + 1, half * 2, butterfly, butterfly);
+    inv_depth_first_scalar32(p, data + n / 2, n / 2, inv_twid, inv_twid_shoup, depth + 1, half * 2 + 1,
+                             butterfly, butterfly);
+    size_t t = n / 2, m = 1;
+    size_t w_idx = (m << depth) + m * half;
+    uint32_t neg_p = (uint32_t)0 - p, two_p = 2 * p;
+    uint32_t w = inv_twid[w_idx], ws = inv_twid_shoup[w_idx];
+    for (size_t j = 0; j < t; ++j) {
+        pair32 r = last_butterfly(data[j], data[t + j], w, ws, p, neg_p, two_p);
+        data[j] = r.a;
+        data[t + j] = r.b;
+    }
+}
+
+/* src/prime32/generic.rs:9-31 */
+static inline uint32_t gen_add32(uint32_t p, uint32_t a, uint32_t b) {
+    uint32_t neg_b = p - b;
+    return (a >= neg_b) ? a - neg_b : a + b;
+}
+static inline uint32_t gen_sub32(uint32_t p, uint32_t a, uint32_t b) {
+    uint32_t neg_b = p - b;
+    return (a >= b) ? a - b : a + neg_b;
+}
+static inline uint32_t gen_mul32(uint32_t p, uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) % p); }
+
+/* src/prime32/generic.rs:228-260 */
+static void gen_fwd_breadth_first32(uint32_t *data, size_t n, uint32_t p, const uint32_t *twid, size_t depth,
+                                    size_t half) {
+    size_t t = n / 2, m = 1;
+    size_t w_idx = (m << depth) + half * m;
+    while (m < n) {
+        const uint32_t *w = twid + w_idx;
+        for (size_t blk = 0; blk < n / (2 * t); ++blk) {
+            uint32_t *z0 = data + blk * 2 * t, *z1 = z0 + t;
+            uint32_t w1 = w[blk];
+            for (size_t j = 0; j < t; ++j) {
+                uint32_t z1w = gen_mul32(p, z1[j], w1);
+                uint32_t a = gen_add32(p, z0[j], z1w), b = gen_sub32(p, z0[j], z1w);
+                z0[j] = a;
+                z1[j] = b;
+            }
+        }
+        t /= 2;
+        m *= 2;
+        w_idx *= 2;
+    }
+}
+/* src/prime32/generic.rs:262-310 */
+static void gen_fwd_depth_first32(uint32_t *data, size_t n, uint32_t p, const uint32_t *twid, size_t depth,
+                                  size_t half) {
+    if (n <= RECURSION_THRESHOLD32) {
+        gen_fwd_breadth_first32(data, n, p, twid, depth, half);
+        return;
+    }
+    size_t t = n / 2, m = 1;
+    size_t w_idx = (m << depth) + m * half;
+    uint32_t w1 = twid[w_idx];
+    for (size_t j = 0; j < t; ++j) {
+        uint32_t z1w = gen_mul32(p, data[t + j], w1);
+        uint32_t a = gen_add32(p, data[j], z1w), b = gen_sub32(p, data[j], z1w);
+        data[j] = a;
+        data[t + j] = b;
+    }
+    gen_fwd_depth_first32(data, n / 2, p, twid, depth + 1, half * 2);
+    gen_fwd_depth_first32(data + n / 2, n / 2, p, twid, depth + 1, half * 2 + 1);
+}
+/* src/prime32/generic.rs:312-343 */
+static void gen_inv_breadth_first32(uint32_t *data, size_t n, uint32_t p, const uint32_t *inv_twid,
+                                    size_t depth, size_t half) {
+    size_t t = 1, m = n;
+    size_t w_idx = (m << depth) + half * m;
+    while (m > 1) {
+        m /= 2;
+        w_idx /= 2;
+        const uint32_t *w = inv_twid + w_idx;
+        for (size_t blk = 0; blk < n / (2 * t); ++blk) {
+            uint32_t *z0 = data + blk * 2 * t, *z1 = z0 + t;
+            uint32_t w1 = w[blk];
+            for (size_t j = 0; j < t; ++j) {
+                uint32_t a = gen_add32(p, z0[j], z1[j]);
+                uint32_t b = gen_mul32(p, gen_sub32(p, z0[j], z1[j]), w1);
+                z0[j] = a;
+                z1[j] = b;
+            }
+        }
+        t *= 2;
+    }
+}
+/* src/prime32/generic.rs:345-390 */
+static void gen_inv_depth_first32(uint32_t *data, size_t n, uint32_t p, const uint32_t *inv_twid, size_t depth,
+                                  size_t half) {
+    if (n <= RECURSION_THRESHOLD32) {
+        gen_inv_breadth_first32(data, n, p, inv_twid, depth, half);
+        return;
+    }
+    gen_inv_depth_first32(data, n / 2, p, inv_twid, depth + 1, half * 2);
+    gen_inv_depth_first32(data + n / 2, n / 2, p, inv_twid, depth + 1, half * 2 + 1);
+    size_t t = n / 2, m = 1;
+    size_t w_idx = (m << depth) + m * half;
+    uint32_t w1 = inv_twid[w_idx];
+    for (size_t j = 0; j < t; ++j) {
+        uint32_t a = gen_add32(p, data[j], data[t + j]);
+        uint32_t b = gen_mul32(p, gen_sub32(p, data[j], data[t + j]), w1);
+        data[j] = a;
+        data[t + j] = b;
+    }
+}
+
+void orc_plan32_fwd(const orc_plan32 *plan, uint32_t *buf) { /* src/prime32.rs:709-755 */
+    uint32_t p = plan->p;
+    size_t n = plan->n;
+    if (p < ((uint32_t)1 << 30))
+        fwd_depth_first_scalar32(p, buf, n, plan->twid, plan->twid_shoup, 0, 0, fwd_bfly30, fwd_last_bfly30);
+    else if (p < ((uint32_t)1 << 31))
+        fwd_depth_first_scalar32(p, buf, n, plan->twid, plan->twid_shoup, 0, 0, fwd_bfly31, fwd_last_bfly31);
+    else
+        gen_fwd_depth_first32(buf, n, p, plan->twid, 0, 0);
+}
+
+void orc_plan32_inv(const orc_plan32 *plan, uint32_t *buf) { /* src/prime32.rs:762-808 */
+    uint32_t p = plan->p;
+    size_t n = plan->n;
+    if (p < ((uint32_t)1 << 30))
+        inv_depth_first_scalar32(p, buf, n, plan->inv_twid, plan->inv_twid_shoup, 0, 0, inv_bfly30,
+                                 inv_last_bfly30);
+    else if (p < ((uint32_t)1 << 31))
+        inv_depth_first_scalar32(p, buf, n, plan->inv_twid, plan->inv_twid_shoup, 0, 0, inv_bfly31, inv_bfly31);
+    else
+        gen_inv_depth_first32(buf, n, p, plan->inv_twid, 0, 0);
+}
+
+void orc_plan32_mul_assign_normalize(const orc_plan32 *plan, uint32_t *lhs, const uint32_t *rhs, size_t len) {
+    uint32_t p = plan->p;
+    if (p < ((uint32_t)1 << 31)) { /* src/prime32.rs:383-408 */
+        uint32_t big_q_m1 = plan->big_q - 1;
+        for (size_t i = 0; i < len; ++i) {
+            uint64_t d = (uint64_t)lhs[i] * rhs[i];
+            uint32_t c1 = (uint32_t)(d >> big_q_m1);
+            uint32_t c3 = (uint32_t)(((uint64_t)c1 * plan->p_barrett) >> 32);
+            uint32_t prod = (uint32_t)d - p * c3;
+            uint32_t shoup_q = (uint32_t)(((uint64_t)prod * plan->n_inv_mod_p_shoup) >> 32);
+            uint32_t t = prod * plan->n_inv_mod_p - shoup_q * p;
+            lhs[i] = min32(t, t - p);
+        }
+    } else { /* :852-863 */
+        for (size_t i = 0; i < len; ++i) {
+            uint32_t prod = gen_mul32(p, lhs[i], rhs[i]);
+            lhs[i] = gen_mul32(p, prod, plan->n_inv_mod_p);
+        }
+    }
+}
+
+void orc_plan32_normalize(const orc_plan32 *plan, uint32_t *values, size_t len) {
+    uint32_t p = plan->p;
+    if (p < ((uint32_t)1 << 31)) { /* src/prime32.rs:477-488 */
+        for (size_t i = 0; i < len; ++i) {
+            uint32_t val = values[i];
+            uint32_t shoup_q = (uint32_t)(((uint64_t)val * plan->n_inv_mod_p_shoup) >> 32);
+            uint32_t t = val * plan->n_inv_mod_p - shoup_q * p;
+            values[i] = min32(t, t - p);
+        }
+    } else { /* :890-898 */
+        for (size_t i = 0; i < len; ++i) values[i] = gen_mul32(p, values[i], plan->n_inv_mod_p);
+    }
+}
+
+void orc_plan32_mul_accumulate(const orc_plan32 *plan, uint32_t *acc, const uint32_t *lhs, const uint32_t *rhs,
+                               size_t len) {
+    uint32_t p = plan->p;
+    if (p < ((uint32_t)1 << 31)) { /* src/prime32.rs:575-598 */
+        uint32_t big_q_m1 = plan->big_q - 1;
+        for (size_t i = 0; i < len; ++i) {
+            uint64_t d = (uint64_t)lhs[i] * rhs[i];
+            uint32_t c1 = (uint32_t)(d >> big_q_m1);
+            uint32_t c3 = (uint32_t)(((uint64_t)c1 * plan->p_barrett) >> 32);
+            uint32_t prod = (uint32_t)d - p * c3;
+            prod = min32(prod, prod - p);
+            uint32_t acc_ = prod + acc[i];
+            acc[i] = min32(acc_, acc_ - p);
+        }
+    } else { /* :917-925 */
+        for (size_t i = 0; i < len; ++i) {
+            uint32_t prod = gen_mul32(p, lhs[i], rhs[i]);
+            acc[i] = gen_add32(p, acc[i], prod);
+        }
+    }
+}
+
+/* ========================================================================= */
+/* CRT constants: src/lib.rs:447-652 (const fn there; computed on first use)  */
+/* ========================================================================= */
+static const uint32_t P32[10] = {
+    0x3F5A0001u, 0x3F5D0001u, 0x3F760001u, 0x3F820001u, 0x3FAC0001u, /* src/lib.rs:453-457 */
+    0x3FAF0001u, 0x3FB10001u, 0x3FBB0001u, 0x3FDE0001u, 0x3FFC0001u, /* src/lib.rs:458-462 */
+};
+static const uint64_t P52[6] = {
+    0x3FFFFFE770001ull, 0x3FFFFFEB90001ull, 0x3FFFFFEC80001ull, /* src/lib.rs:601-603 */
+    0x3FFFFFF8B0001ull, 0x3FFFFFFB80001ull, 0x3FFFFFFC70001ull, /* src/lib.rs:604-606 */
+};
+uint32_t orc_primes32_p(int i) { return P32[i]; }
+uint64_t orc_primes52_p(int i) { return P52[i]; }
+
+static inline uint32_t inv_mod32(uint32_t m, uint32_t x) { return orc_exp_mod32(m, x, m - 2); } /* :491-493 */
+static inline uint64_t shoup64(uint64_t m, uint64_t w) { return (uint64_t)((((u128)w) << 64) / m); } /* :508-510 */
+static inline uint64_t inv_mod64p(uint64_t m, uint64_t x) { return orc_exp_mod64(m, x, m - 2); }     /* :624-626 */
+
+/* src/native32.rs:21-25 (also used as native64::mul_mod32) */
+static inline uint32_t n_mul_mod32(uint32_t p, uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) % p); }
+/* src/native64.rs:36-41 */
+static inline uint64_t n_mul_mod64(uint64_t p_neg, uint64_t a, uint64_t b, uint64_t b_shoup) {
+    uint64_t q = (uint64_t)(((u128)a * b_shoup) >> 64);
+    uint64_t r = a * b + p_neg * q;
+    return min64(r, r + p_neg);
+}
+
+uint32_t orc_reconstruct_32bit_01(uint32_t mod_p0, uint32_t mod_p1) { /* src/native_binary32.rs:22-41 */
+    const uint32_t P0 = P32[0], P1 = P32[1];
+    uint32_t P0_INV_MOD_P1 = inv_mod32(P1, P0);
+    uint32_t v0 = mod_p0;
+    uint32_t v1 = n_mul_mod32(P1, P0_INV_MOD_P1, 2 * P1 + mod_p1 - v0);
+    int sign = v1 > (P1 / 2);
+    uint32_t _0 = P0, _01 = _0 * P1;
+    uint32_t pos = v0 + v1 * _0;
+    uint32_t neg = pos - _01;
+    return sign ? neg : pos;
+}
+
+static void digits_012(uint32_t mod_p0, uint32_t mod_p1, uint32_t mod_p2, uint32_t *v0o, uint32_t *v1o,
+                       uint32_t *v2o) { /* shared head of src/native32.rs:31-38 and src/native_binary64.rs:36-43 */
+    const uint32_t P0 = P32[0], P1 = P32[1], P2 = P32[2];
+    uint32_t P0_INV_MOD_P1 = inv_mod32(P1, P0);
+    uint32_t P01_INV_MOD_P2 = inv_mod32(P2, n_mul_mod32(P2, P0, P1));
+    uint32_t v0 = mod_p0;
+    uint32_t v1 = n_mul_mod32(P1, P0_INV_MOD_P1, 2 * P1 + mod_p1 - v0);
+    uint32_t v2 = n_mul_mod32(P2, P01_INV_MOD_P2, 2 * P2 + mod_p2 - (v0 + n_mul_mod32(P2, P0, v1)));
+    *v0o = v0;
+    *v1o = v1;
+    *v2o = v2;
+}
+
+uint32_t orc_reconstruct_32bit_012_u32(uint32_t m0, uint32_t m1, uint32_t m2) { /* src/native32.rs:28-56 */
+    uint32_t v0, v1, v2;
+    digits_012(m0, m1, m2, &v0, &v1, &v2);
+    int sign = v2 > (P32[2] / 2);
+    uint32_t _0 = P32[0], _01 = _0 * P32[1], _012 = _01 * P32[2];
+    uint32_t pos = v0 + v1 * _0 + v2 * _01;
+    uint32_t neg = pos - _012;
+    return sign ? neg : pos;
+}
+
+uint64_t orc_reconstruct_32bit_012_u64(uint32_t m0, uint32_t m1, uint32_t m2) { /* src/native_binary64.rs:33-61 */
+    uint32_t v0, v1, v2;
+    digits_012(m0, m1, m2, &v0, &v1, &v2);
+    int sign = v2 > (P32[2] / 2);
+    uint64_t _0 = P32[0], _01 = _0 * (uint64_t)P32[1], _012 = _01 * (uint64_t)P32[2];
+    uint64_t pos = (uint64_t)v0 + (uint64_t)v1 * _0 + (uint64_t)v2 * _01;
+    uint64_t neg = pos - _012;
+    return sign ? neg : pos;
+}
+
+/* shared head of src/native64.rs:98-125 and src/native_binary128.rs:20-45 */
+static void digits_0_12_34(const uint32_t m[5], uint64_t *v0o, uint64_t *v12o, uint64_t *v34o, uint64_t *p12o,
+                           uint64_t *p34o) {
+    const uint32_t P0 = P32[0], P1 = P32[1], P2 = P32[2], P3 = P32[3], P4 = P32[4];
+    uint32_t P1_INV_MOD_P2 = inv_mod32(P2, P1);
+    uint32_t P3_INV_MOD_P4 = inv_mod32(P4, P3);
+    uint64_t P12 = (uint64_t)P1 * P2, P34 = (uint64_t)P3 * P4; /* src/lib.rs:539-540 */
+    /* src/lib.rs:541-551: inverse through Euler's theorem, phi(P12) = (P1-1)(P2-1) */
+    uint64_t P0_INV_MOD_P12 = orc_exp_mod64(P12, P0, ((uint64_t)P1 - 1) * ((uint64_t)P2 - 1) - 1);
+    uint64_t P0_INV_MOD_P12_SHOUP = shoup64(P12, P0_INV_MOD_P12);
+    uint64_t P0_MOD_P34_SHOUP = shoup64(P34, P0);
+    uint64_t P012_INV_MOD_P34 =
+        orc_exp_mod64(P34, orc_mul_mod64(P34, P0, P12), ((uint64_t)P3 - 1) * ((uint64_t)P4 - 1) - 1);
+    uint64_t P012_INV_MOD_P34_SHOUP = shoup64(P34, P012_INV_MOD_P34);
+
+    uint64_t mod_p12, mod_p34;
+    {
+        uint32_t v1 = m[1];
+        uint32_t v2 = n_mul_mod32(P2, P1_INV_MOD_P2, 2 * P2 + m[2] - v1);
+        mod_p12 = (uint64_t)v1 + ((uint64_t)v2 * P1);
+    }
+    {
+        uint32_t v3 = m[3];
+        uint32_t v4 = n_mul_mod32(P4, P3_INV_MOD_P4, 2 * P4 + m[4] - v3);
+        mod_p34 = (uint64_t)v3 + ((uint64_t)v4 * P3);
+    }
+    uint64_t v0 = m[0];
+    uint64_t v12 = n_mul_mod64((uint64_t)0 - P12, 2 * P12 + mod_p12 - v0, P0_INV_MOD_P12, P0_INV_MOD_P12_SHOUP);
+    uint64_t v34 = n_mul_mod64((uint64_t)0 - P34,
+                               2 * P34 + mod_p34 - (v0 + n_mul_mod64((uint64_t)0 - P34, v12, P0, P0_MOD_P34_SHOUP)),
+                               P012_INV_MOD_P34, P012_INV_MOD_P34_SHOUP);
+    *v0o = v0;
+    *v12o = v12;
+    *v34o = v34;
+    *p12o = P12;
+    *p34o = P34;
+}
+
+uint64_t orc_reconstruct_32bit_01234_v2_u64(const uint32_t m[5]) { /* src/native64.rs:91-141 */
+    uint64_t v0, v12, v34, P12, P34;
+    digits_0_12_34(m, &v0, &v12, &v34, &P12, &P34);
+    int sign = v34 > (P34 / 2);
+    uint64_t _0 = P32[0], _012 = _0 * P12, _01234 = _012 * P34;
+    uint64_t pos = v0 + v12 * _0 + v34 * _012;
+    uint64_t neg = pos - _01234;
+    return sign ? neg : pos;
+}
+
+orc_u128 orc_reconstruct_32bit_01234_v2_u128(const uint32_t m[5]) { /* src/native_binary128.rs:13-63 */
+    uint64_t v0, v12, v34, P12, P34;
+    digits_0_12_34(m, &v0, &v12, &v34, &P12, &P34);
+    int sign = v34 > (P34 / 2);
+    u128 _0 = P32[0], _012 = _0 * (u128)P12, _01234 = _012 * (u128)P34;
+    u128 pos = (u128)v0 + (u128)v12 * _0 + (u128)v34 * _012;
+    u128 neg = pos - _01234;
+    return sign ? neg : pos;
+}
+
+orc_u128 orc_reconstruct_32bit_0123456789_v2(const uint32_t m[10]) { /* src/native128.rs:20-118 */
+    const uint32_t *P = P32;
+    uint64_t modp[5]; /* mod_p01, mod_p23, mod_p45, mod_p67, mod_p89 : :34-58 */
+    for (int k = 0; k < 5; ++k) {
+        uint32_t pa = P[2 * k], pb = P[2 * k + 1];
+        uint32_t inv = inv_mod32(pb, pa); /* P0_INV_MOD_P1, P2_INV_MOD_P3, ... src/lib.rs:554-561 */
+        uint32_t va = m[2 * k];
+        uint32_t vb = n_mul_mod32(pb, inv, 2 * pb + m[2 * k + 1] - va);
+        modp[k] = (uint64_t)va + ((uint64_t)vb * pa);
+    }
+    uint64_t P01 = (uint64_t)P[0] * P[1], P23 = (uint64_t)P[2] * P[3], P45 = (uint64_t)P[4] * P[5],
+             P67 = (uint64_t)P[6] * P[7], P89 = (uint64_t)P[8] * P[9]; /* src/lib.rs:563-567 */
+    /* src/lib.rs:569-595 */
+    uint64_t P01_MOD_P45_SHOUP = shoup64(P45, P01), P01_MOD_P67_SHOUP = shoup64(P67, P01),
+             P01_MOD_P89_SHOUP = shoup64(P89, P01);
+    uint64_t P23_MOD_P67_SHOUP = shoup64(P67, P23), P23_MOD_P89_SHOUP = shoup64(P89, P23);
+    uint64_t P45_MOD_P89_SHOUP = shoup64(P89, P45);
+    uint64_t P01_INV_MOD_P23 = orc_exp_mod64(P23, P01, ((uint64_t)P[2] - 1) * ((uint64_t)P[3] - 1) - 1);
+    uint64_t P0123_INV_MOD_P45 =
+        orc_exp_mod64(P45, orc_mul_mod64(P45, P01, P23), ((uint64_t)P[4] - 1) * ((uint64_t)P[5] - 1) - 1);
+    uint64_t P012345_INV_MOD_P67 =
+        orc_exp_mod64(P67, orc_mul_mod64(P67, orc_mul_mod64(P67, P01, P23), P45),
+                      ((uint64_t)P[6] - 1) * ((uint64_t)P[7] - 1) - 1);
+    uint64_t P01234567_INV_MOD_P89 =
+        orc_exp_mod64(P89, orc_mul_mod64(P89, orc_mul_mod64(P89, orc_mul_mod64(P89, P01, P23), P45), P67),
+                      ((uint64_t)P[8] - 1) * ((uint64_t)P[9] - 1) - 1);
+    uint64_t nP23 = (uint64_t)0 - P23, nP45 = (uint64_t)0 - P45, nP67 = (uint64_t)0 - P67, nP89 = (uint64_t)0 - P89;
+
+    uint64_t v01 = modp[0];
+    uint64_t v23 = n_mul_mod64(nP23, 2 * P23 + modp[1] - v01, P01_INV_MOD_P23, shoup64(P23, P01_INV_MOD_P23));
+    uint64_t v45 = n_mul_mod64(nP45, 2 * P45 + modp[2] - (v01 + n_mul_mod64(nP45, v23, P01, P01_MOD_P45_SHOUP)),
+                               P0123_INV_MOD_P45, shoup64(P45, P0123_INV_MOD_P45));
+    uint64_t v67 = n_mul_mod64(
+        nP67,
+        2 * P67 + modp[3] -
+            (v01 + n_mul_mod64(nP67, v23 + n_mul_mod64(nP67, v45, P23, P23_MOD_P67_SHOUP), P01, P01_MOD_P67_SHOUP)),
+        P012345_INV_MOD_P67, shoup64(P67, P012345_INV_MOD_P67));
+    uint64_t v89 = n_mul_mod64(
+        nP89,
+        2 * P89 + modp[4] -
+            (v01 + n_mul_mod64(nP89,
+                               v23 + n_mul_mod64(nP89, v45 + n_mul_mod64(nP89, v67, P45, P45_MOD_P89_SHOUP), P23,
+                                                 P23_MOD_P89_SHOUP),
+                               P01, P01_MOD_P89_SHOUP)),
+        P01234567_INV_MOD_P89, shoup64(P89, P01234567_INV_MOD_P89));
+
+    int sign = v89 > (P89 / 2);
+    u128 P0123 = (u128)P01 * (u128)P23;   /* src/lib.rs:592 */
+    u128 P012345 = P0123 * (u128)P45;     /* :593 */
+    u128 P01234567 = P012345 * (u128)P67; /* :594 */
+    u128 P0123456789 = P01234567 * (u128)P89; /* :595 (wrapping) */
+    u128 pos = (u128)v01 + (u128)v23 * (u128)P01 + (u128)v45 * P0123 + (u128)v67 * P012345 +
+               (u128)v89 * P01234567;
+    u128 neg = pos - P0123456789;
+    return sign ? neg : pos;
+}
+
+/* ---- 52-bit plans.  The reference implements these only with AVX-512 IFMA
+ * (mul_mod52_avx512, src/native32.rs:96-107: Shoup product on 52-bit lanes followed by one
+ * conditional subtraction => canonical a*b mod p).  Restated as exact arithmetic. ---- */
+static inline uint64_t mul_mod52(uint64_t p, uint64_t a, uint64_t b) { return (uint64_t)(((u128)a * b) % p); }
+
+uint32_t orc_reconstruct_52bit_0(uint64_t mod_p0) { /* src/native_binary32.rs:111-125 */
+    uint64_t P0 = P52[0];
+    int sign = mod_p0 > (P0 / 2);
+    uint64_t pos = mod_p0, neg = pos - P0;
+    return (uint32_t)(sign ? neg : pos);
+}
+static uint64_t rec52_01(uint64_t mod_p0, uint64_t mod_p1) { /* src/native32.rs:223-253, native_binary64.rs:230-260 */
+    uint64_t P0 = P52[0], P1 = P52[1];
+    uint64_t P0_INV_MOD_P1 = inv_mod64p(P1, P0);
+    uint64_t v0 = mod_p0;
+    uint64_t v1 = mul_mod52(P1, 2 * P1 + mod_p1 - v0, P0_INV_MOD_P1);
+    int sign = v1 > (P1 / 2);
+    uint64_t pos = v0 + v1 * P0;
+    uint64_t neg = pos - P0 * P1;
+    return sign ? neg : pos;
+}
+uint32_t orc_reconstruct_52bit_01_u32(uint64_t m0, uint64_t m1) { return (uint32_t)rec52_01(m0, m1); }
+uint64_t orc_reconstruct_52bit_01_u64(uint64_t m0, uint64_t m1) { return rec52_01(m0, m1); }
+uint64_t orc_reconstruct_52bit_012(uint64_t mod_p0, uint64_t mod_p1, uint64_t mod_p2) { /* src/native64.rs:770-829 */
+    uint64_t P0 = P52[0], P1 = P52[1], P2 = P52[2];
+    uint64_t P0_INV_MOD_P1 = inv_mod64p(P1, P0);
+    uint64_t P01_INV_MOD_P2 = inv_mod64p(P2, mul_mod52(P2, P0, P1));
+    uint64_t v0 = mod_p0;
+    uint64_t v1 = mul_mod52(P1, 2 * P1 + mod_p1 - v0, P0_INV_MOD_P1);
+    uint64_t v2 = mul_mod52(P2, 2 * P2 + mod_p2 - (v0 + mul_mod52(P2, v1, P0)), P01_INV_MOD_P2);
+    int sign = v2 > (P2 / 2);
+    uint64_t pos = v0 + v1 * P0 + v2 * (P0 * P1);
+    uint64_t neg = pos - P0 * P1 * P2;
+    return sign ? neg : pos;
+}
+
+/* ========================================================================= */
+/* native plans                                                              */
+/* ========================================================================= */
+orc_native *orc_native_try_new(orc_native_kind kind, size_t n) {
+    static const int NPR[10] = {3, 5, 10, 2, 3, 5, 2, 3, 1, 2};
+    static const int WORD[10] = {4, 8, 16, 4, 8, 16, 4, 8, 4, 8};
+    orc_native *pl = (orc_native *)calloc(1, sizeof(*pl));
+    pl->kind = kind;
+    pl->n = n;
+    pl->nprimes = NPR[kind];
+    pl->word = WORD[kind];
+    pl->is52 = kind >= ORC_NATIVE32_PLAN52;
+    pl->binary = (kind >= ORC_NATIVE_BINARY32_PLAN32 && kind <= ORC_NATIVE_BINARY128_PLAN32) ||
+                 kind == ORC_NATIVE_BINARY32_PLAN52 || kind == ORC_NATIVE_BINARY64_PLAN52;
+    for (int i = 0; i < pl->nprimes; ++i) {
+        if (pl->is52) {
+            pl->p64[i] = orc_plan64_try_new(n, P52[i], NULL);
+            if (!pl->p64[i]) {
+                orc_native_free(pl);
+                return NULL;
+            }
+        } else {
+            pl->p32[i] = orc_plan32_try_new(n, P32[i], NULL); /* `?` propagation: src/native64.rs:933-942 */
+            if (!pl->p32[i]) {
+                orc_native_free(pl);
+                return NULL;
+            }
+        }
+    }
+    return pl;
+}
+
+void orc_native_free(orc_native *pl) {
+    if (!pl) return;
+    for (int i = 0; i < 10; ++i) orc_plan32_free(pl->p32[i]);
+    for (int i = 0; i < 3; ++i) orc_plan64_free(pl->p64[i]);
+    free(pl);
+}
+
+static inline u128 load_word(const void *v, int word, size_t i) {
+    if (word == 4) return ((const uint32_t *)v)[i];
+    if (word == 8) return ((const uint64_t *)v)[i];
+    u128 x;
+    memcpy(&x, (const char *)v + 16 * i, 16); /* u128 as Rust lays it out on x86-64: 16-byte little-endian */
+    return x;
+}
+static inline void store_word(void *v, int word, size_t i, u128 x) {
+    if (word == 4)
+        ((uint32_t *)v)[i] = (uint32_t)x;
+    else if (word == 8)
+        ((uint64_t *)v)[i] = (uint64_t)x;
+    else
+        memcpy((char *)v + 16 * i, &x, 16);
+}
+
+static void native_split(const orc_native *pl, const void *value, void *const *res, int binary) {
+    size_t n = pl->n;
+    for (size_t i = 0; i < n; ++i) {
+        u128 v = load_word(value, pl->word, i);
+        for (int k = 0; k < pl->nprimes; ++k) {
+            if (pl->is52) {
+                /* src/native64.rs:1113-1119 (value % P_i); src/native32.rs:447-452 and
+                 * src/native_binary32.rs:272-279 copy the u32 (always < P_i);
+                 * fwd_binary: src/native_binary64.rs:481-487 plain copy */
+                uint64_t r = (binary || pl->word == 4) ? (uint64_t)v : (uint64_t)(v % P52[k]);
+                ((uint64_t *)res[k])[i] = r;
+            } else {
+                /* src/native64.rs:980-993 (value % P_i);
+                 * fwd_binary: src/native_binary64.rs:379-385 `*value as u32` */
+                uint32_t r = binary ? (uint32_t)v : (uint32_t)(v % P32[k]);
+                ((uint32_t *)res[k])[i] = r;
+            }
+        }
+    }
+    for (int k = 0; k < pl->nprimes; ++k) {
+        if (pl->is52)
+            orc_plan64_fwd(pl->p64[k], (uint64_t *)res[k]);
+        else
+            orc_plan32_fwd(pl->p32[k], (uint32_t *)res[k]);
+    }
+}
+
+void orc_native_fwd(const orc_native *pl, const void *value, void *const *res) { native_split(pl, value, res, 0); }
+void orc_native_fwd_binary(const orc_native *pl, const void *value, void *const *res) {
+    native_split(pl, value, res, 1);
+}
+
+void orc_native_inv(const orc_native *pl, void *value, void *const *res) {
+    size_t n = pl->n;
+    for (int k = 0; k < pl->nprimes; ++k) {
+        if (pl->is52)
+            orc_plan64_inv(pl->p64[k], (uint64_t *)res[k]);
+        else
+            orc_plan32_inv(pl->p32[k], (uint32_t *)res[k]);
+    }
+    for (size_t i = 0; i < n; ++i) {
+        uint32_t m[10];
+        uint64_t m64[3];
+        for (int k = 0; k < pl->nprimes; ++k) {
+            if (pl->is52)
+                m64[k] = ((uint64_t *)res[k])[i];
+            else
+                m[k] = ((uint32_t *)res[k])[i];
+        }
+        u128 out = 0;
+        switch (pl->kind) {
+        case ORC_NATIVE32_PLAN32: out = orc_reconstruct_32bit_012_u32(m[0], m[1], m[2]); break;
+        case ORC_NATIVE64_PLAN32: out = orc_reconstruct_32bit_01234_v2_u64(m); break;
+        case ORC_NATIVE128_PLAN32: out = orc_reconstruct_32bit_0123456789_v2(m); break;
+        case ORC_NATIVE_BINARY32_PLAN32: out = orc_reconstruct_32bit_01(m[0], m[1]); break;
+        case ORC_NATIVE_BINARY64_PLAN32: out = orc_reconstruct_32bit_012_u64(m[0], m[1], m[2]); break;
+        case ORC_NATIVE_BINARY128_PLAN32: out = orc_reconstruct_32bit_01234_v2_u128(m); break;
+        case ORC_NATIVE32_PLAN52: out = orc_reconstruct_52bit_01_u32(m64[0], m64[1]); break;
+        case ORC_NATIVE64_PLAN52: out = orc_reconstruct_52bit_012(m64[0], m64[1], m64[2]); break;
+        case ORC_NATIVE_BINARY32_PLAN52: out = orc_reconstruct_52bit_0(m64[0]); break;
+        case ORC_NATIVE_BINARY64_PLAN52: out = orc_reconstruct_52bit_01_u64(m64[0], m64[1]); break;
+        }
+        store_word(value, pl->word, i, out);
+    }
+}
+
+void orc_native_negacyclic_polymul(const orc_native *pl, void *prod, const void *lhs, const void *rhs) {
+    /* src/native64.rs:1042-1069: 2k temporaries, fwd lhs, fwd (or fwd_binary) rhs, k pointwise, inv */
+    size_t n = pl->n;
+    size_t rb = pl->is52 ? 8 : 4;
+    void *l[10], *r[10];
+    for (int k = 0; k < pl->nprimes; ++k) {
+        l[k] = xaligned(n * rb);
+        r[k] = xaligned(n * rb);
+    }
+    orc_native_fwd(pl, lhs, l);
+    if (pl->binary)
+        orc_native_fwd_binary(pl, rhs, r);
+    else
+        orc_native_fwd(pl, rhs, r);
+    for (int k = 0; k < pl->nprimes; ++k) {
+        if (pl->is52)
+            orc_plan64_mul_assign_normalize(pl->p64[k], (uint64_t *)l[k], (const uint64_t *)r[k], n);
+        else
+            orc_plan32_mul_assign_normalize(pl->p32[k], (uint32_t *)l[k], (const uint32_t *)r[k], n);
+    }
+    orc_native_inv(pl, prod, l);
+    for (int k = 0; k < pl->nprimes; ++k) {
+        free(l[k]);
+        free(r[k]);
+    }
+}
+
+/* ========================================================================= */
+/* schoolbook negacyclic convolution: src/prime64.rs:1143-1182               */
+/* ========================================================================= */
+static inline uint64_t t_add64(uint64_t p, uint64_t a, uint64_t b) {
+    uint64_t neg_b = p - b; /* wrapping_sub; p == 0 -> wrapping arithmetic */
+    return (a >= neg_b) ? a - neg_b : a + b;
+}
+static inline uint64_t t_sub64(uint64_t p, uint64_t a, uint64_t b) {
+    uint64_t neg_b = p - b;
+    return (a >= b) ? a - b : a + neg_b;
+}
+static inline uint64_t t_mul64(uint64_t p, uint64_t a, uint64_t b) {
+    u128 wide = (u128)a * b;
+    return p == 0 ? (uint64_t)wide : (uint64_t)(wide % p);
+}
+void orc_negacyclic_convolution64(size_t n, uint64_t p, const uint64_t *lhs, const uint64_t *rhs, uint64_t *out) {
+    uint64_t *full = (uint64_t *)calloc(2 * n, 8);
+    for (size_t i = 0; i < n; ++i)
+        for (size_t j = 0; j < n; ++j) full[i + j] = t_add64(p, full[i + j], t_mul64(p, lhs[i], rhs[j]));
+    for (size_t i = 0; i < n; ++i) out[i] = t_sub64(p, full[i], full[i + n]);
+    free(full);
+}
+void orc_negacyclic_convolution32(size_t n, uint32_t p, const uint32_t *lhs, const uint32_t *rhs, uint32_t *out) {
+    /* src/prime32.rs tests module: same shape on u32 (p == 0 -> wrapping mod 2^32) */
+    uint32_t *full = (uint32_t *)calloc(2 * n, 4);
+    for (size_t i = 0; i < n; ++i)
+        for (size_t j = 0; j < n; ++j) {
+            uint64_t wide = (uint64_t)lhs[i] * rhs[j];
+            uint32_t m = p == 0 ? (uint32_t)wide : (uint32_t)(wide % p);
+            uint32_t a = full[i + j], neg_b = p - m;
+            full[i + j] = (a >= neg_b) ? a - neg_b : a + m;
+        }
+    for (size_t i = 0; i < n; ++i) {
+        uint32_t a = full[i], b = full[i + n], neg_b = p - b;
+        out[i] = (a >= b) ? a - b : a + neg_b;
+    }
+    free(full);
+}
+void orc_negacyclic_convolution128(size_t n, const orc_u128 *lhs, const orc_u128 *rhs, orc_u128 *out) {
+    /* src/native128.rs:359-372: wrapping u128 */
+    u128 *full = (u128 *)calloc(2 * n, 16);
+    for (size_t i = 0; i < n; ++i)
+        for (size_t j = 0; j < n; ++j) full[i + j] += lhs[i] * rhs[j];
+    for (size_t i = 0; i < n; ++i) out[i] = full[i] - full[i + n];
+    free(full);
+}
+
+/* ========================================================================= */
+/* synthetic inputs (shared definition with the GPU fill kernel)             */
+/* ========================================================================= */
+uint64_t orc_splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+void orc_fill_uniform_u64(uint64_t *dst, size_t count, uint64_t bound, uint64_t seed) {
+    for (size_t i = 0; i < count; ++i) {
+        uint64_t r = orc_splitmix64(seed + i);
+        dst[i] = bound ? (uint64_t)(((u128)r * bound) >> 64) : r;
+    }
+}
+void orc_fill_uniform_u32(uint32_t *dst, size_t count, uint32_t bound, uint64_t seed) {
+    for (size_t i = 0; i < count; ++i) {
+        uint64_t r = orc_splitmix64(seed + i);
+        dst[i] = bound ? (uint32_t)(((r >> 32) * (uint64_t)bound) >> 32) : (uint32_t)(r >> 32);
+    }
+}
+
+/* ========================================================================= */
+/* batched drivers                                                           */
+/* ========================================================================= */
+typedef struct {
+    int op; /* 0 fwd64 1 inv64 2 mul64 3 fwd32 4 inv32 5 native polymul */
+    const void *plan;
+    void *a;
+    const void *b;
+    const void *c;
+    size_t begin, end;
+} job_t;
+
+static void *job_main(void *arg) {
+    job_t *j = (job_t *)arg;
+    for (size_t i = j->begin; i < j->end; ++i) {
+        switch (j->op) {
+        case 0: {
+            const orc_plan64 *pl = (const orc_plan64 *)j->plan;
+            orc_plan64_fwd(pl, (uint64_t *)j->a + i * pl->n);
+        } break;
+        case 1: {
+            const orc_plan64 *pl = (const orc_plan64 *)j->plan;
+            orc_plan64_inv(pl, (uint64_t *)j->a + i * pl->n);
+        } break;
+        case 2: {
+            const orc_plan64 *pl = (const orc_plan64 *)j->plan;
+            orc_plan64_mul_assign_normalize(pl, (uint64_t *)j->a + i * pl->n, (const uint64_t *)j->b + i * pl->n,
+                                            pl->n);
+        } break;
+        case 3: {
+            const orc_plan32 *pl = (const orc_plan32 *)j->plan;
+            orc_plan32_fwd(pl, (uint32_t *)j->a + i * pl->n);
+        } break;
+        case 4: {
+            const orc_plan32 *pl = (const orc_plan32 *)j->plan;
+            orc_plan32_inv(pl, (uint32_t *)j->a + i * pl->n);
+        } break;
+        case 5: {
+            const orc_native *pl = (const orc_native *)j->plan;
+            size_t stride = pl->n * (size_t)pl->word;
+            orc_native_negacyclic_polymul(pl, (char *)j->a + i * stride, (const char *)j->b + i * stride,
+                                          (const char *)j->c + i * stride);
+        } break;
+        }
+    }
+    return NULL;
+}
+
+static double now_s(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+static double run_batch(int op, const void *plan, void *a, const void *b, const void *c, size_t batch, int nthreads) {
+    if (nthreads < 1) nthreads = 1;
+    if ((size_t)nthreads > batch) nthreads = batch ? (int)batch : 1;
+    job_t *jobs = (job_t *)calloc((size_t)nthreads, sizeof(job_t));
+    pthread_t *th = (pthread_t *)calloc((size_t)nthreads, sizeof(pthread_t));
+    double t0 = now_s();
+    for (int t = 0; t < nthreads; ++t) {
+        jobs[t] = (job_t){op, plan, a, b, c, batch * (size_t)t / (size_t)nthreads,
+                          batch * (size_t)(t + 1) / (size_t)nthreads};
+        if (nthreads == 1)
+            job_main(&jobs[t]);
+        else
+            pthread_create(&th[t], NULL, job_main, &jobs[t]);
+    }
+    if (nthreads > 1)
+        for (int t = 0; t < nthreads; ++t) pthread_join(th[t], NULL);
+    double t1 = now_s();
+    free(jobs);
+    free(th);
+    return t1 - t0;
+}
+
+double orc_plan64_fwd_batch(const orc_plan64 *plan, uint64_t *bufs, size_t batch, int nthreads) {
+    return run_batch(0, plan, bufs, NULL, NULL, batch, nthreads);
+}
+double orc_plan64_inv_batch(const orc_plan64 *plan, uint64_t *bufs, size_t batch, int nthreads) {
+    return run_batch(1, plan, bufs, NULL, NULL, batch, nthreads);
+}
+double orc_plan64_mul_assign_normalize_batch(const orc_plan64 *plan, uint64_t *lhs, const uint64_t *rhs,
+                                             size_t batch, int nthreads) {
+    return run_batch(2, plan, lhs, rhs, NULL, batch, nthreads);
+}
+double orc_plan32_fwd_batch(const orc_plan32 *plan, uint32_t *bufs, size_t batch, int nthreads) {
+    return run_batch(3, plan, bufs, NULL, NULL, batch, nthreads);
+}
+double orc_plan32_inv_batch(const orc_plan32 *plan, uint32_t *bufs, size_t batch, int nthreads) {
+    return run_batch(4, plan, bufs, NULL, NULL, batch, nthreads);
+}
+double orc_native_negacyclic_polymul_batch(const orc_native *plan, void *prod, const void *lhs, const void *rhs,
+                                           size_t batch, int nthreads) {
+    return run_batch(5, plan, prod, lhs, rhs, batch, nthreads);
+}
