@@ -1,0 +1,165 @@
+#!/usr/bin/env python3
+"""Headline benchmark: forward+inverse NTTs/sec, prime64, N=1024, batched (BASELINE.json).
+
+One step = one pass of the hot path over one device-resident batch (configs[1]):
+    fwd(A)  ->  mul_assign_normalize(A, B^)  ->  inv(A)        A: 65536 polynomials x 1024 x u64 (512 MiB)
+i.e. a negacyclic product against a pre-transformed operand: 2 transforms per polynomial per step
+plus the pointwise pass (which is inside the timed region and earns no units).  Inputs are synthetic
+(splitmix64, generated on the device) and resident in HBM before the timed region starts.
+
+N GPUs: one process per GPU, each owns its own shard of `batch` polynomials (independent units, no
+collective on the data path) -> weak scaling.  Timing: barrier + synchronize on both sides of exactly
+K steps, max over ranks, rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+P62 = 4611686018427322369   # benches/ntt.rs:115  largest prime = 1 mod 2^16 below 2^62
+N = 1024
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(n, p, seconds_budget=12.0):
+    """The oracle (a C restatement of the reference's scalar CPU path; the Rust crate itself cannot be
+    built in this image) timed on this host's cores on a bounded sample of the same workload."""
+    import numpy as np
+    from oracle import pyoracle
+    try:
+        pyoracle.build(native=True)   # -march=native for the machine that does the timing
+        native = True
+    except Exception:
+        native = False
+    plan = pyoracle.Plan.try_new(n, p, 64, native=native)
+    cores = os.cpu_count() or 1
+    sample = 16384
+    buf = pyoracle.fill_uniform(sample * n, p, 0x5EED0002, 64)
+    # single thread (the reference's criterion harness is single-threaded: benches/ntt.rs:94-105)
+    t1 = plan.fwd_batch(buf, 1) + plan.inv_batch(buf, 1)
+    single = 2 * sample / t1
+    # all host threads, repeated until ~half the budget is used
+    reps, tot, done = 0, 0.0, 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds_budget / 2 and reps < 64:
+        tot += plan.fwd_batch(buf, cores) + plan.inv_batch(buf, cores)
+        done += 2 * sample
+        reps += 1
+    multi = done / tot
+    return {
+        "value": multi, "unit": "NTT/s", "cores": cores, "kind": "port",
+        "sample": "%d polynomials x (fwd+inv), N=%d, p=%d, %d repetitions on %d threads; "
+                  "single-thread rate %.0f NTT/s; %s build of oracle/cntt_oracle.c" % (
+                      sample, n, p, reps, cores, single, "-O3 -march=native" if native else "-O3 portable"),
+        "single_thread_value": single,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=65536, help="polynomials per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import concrete_ntt_amd as cntt
+    from concrete_ntt_amd import prime64
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    batch = args.batch
+    plan = prime64.Plan.try_new(N, P62)
+    dev = torch.device("cuda", local_rank)
+    a = torch.empty(batch * N, dtype=torch.int64, device=dev)
+    b = torch.empty(batch * N, dtype=torch.int64, device=dev)
+    # every rank owns a different shard of the synthetic stream
+    cntt.fill_uniform(a, P62, 0x5EED0002 + rank * batch * N)
+    cntt.fill_uniform(b, P62, 0x5EED1002 + rank * batch * N)
+    plan.fwd_batch(b)   # B^ : the pre-transformed operand
+
+    def step():
+        plan.fwd_batch(a)
+        plan.mul_assign_normalize_batch(a, b)
+        plan.inv_batch(a)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-kernel timing with HIP events on the launch stream (roofline leg), after the timed region
+    reps = 10
+    fwd_ms = plan.time_batch(0, a, reps=reps) / reps
+    inv_ms = plan.time_batch(1, a, reps=reps) / reps
+    mul_ms = plan.time_batch(2, a, rhs=b, reps=reps) / reps
+    alg_bytes = 2 * N * 8 * batch                     # read once + write once per transform
+    achieved = alg_bytes / (fwd_ms * 1e-3) / 1e9
+
+    if rank == 0:
+        units = world * 2 * batch * args.steps        # forward + inverse transforms, all ranks
+        out = {
+            "metric": "forward+inverse NTTs/sec (prime64, N=1024, batched) per GPU; % HBM roofline",
+            "value": units / elapsed, "unit": "NTT/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "prime64 N=1024 p=4611686018427322369 batch=%d per GPU: fwd + "
+                                   "mul_assign_normalize (pre-transformed rhs) + inv, device-resident" % batch,
+                       "polynomial_size": N, "batch_per_gpu": batch, "modulus": P62,
+                       "sharding": "independent batch shards, no collective"},
+            "per_gpu_value": units / elapsed / world,
+            "roofline": {"bound": "hbm", "kernel": "ntt_kernel<u64, LOGN=10, fwd, lazy>",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": fwd_ms,
+                         "inv_kernel_ms": inv_ms, "inv_frac": alg_bytes / (inv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "pointwise_kernel_ms": mul_ms,
+                         "pointwise_frac": 3 * N * 8 * batch / (mul_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(N, P62)
+            except Exception as e:  # the baseline is a reported extra, never a reason to lose the bench line
+                out["cpu_baseline"] = {"value": None, "unit": "NTT/s", "cores": 0, "kind": "port",
+                                       "sample": "failed: %r" % (e,)}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,146 @@
+"""prime32::Plan / prime64::Plan over the C ABI (shared implementation)."""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import Panic, buffer_info, check, lib
+
+
+class PrimePlan:
+    """Negacyclic NTT plan for a prime modulus; mirrors concrete_ntt::prime{32,64}::Plan
+    (src/prime64.rs:221-236, :701-1129 ; src/prime32.rs:601-616, :627-927)."""
+
+    BITS = 64
+
+    def __init__(self, handle, owned=True):
+        self._h, self._owned = handle, owned
+        self._p = "cntt_prime%d_" % self.BITS
+        self._n = getattr(lib(), self._p + "ntt_size")(handle)
+
+    # -- construction ------------------------------------------------------------------------
+    @classmethod
+    def try_new(cls, polynomial_size, modulus):
+        """Plan::try_new -> plan or None; raises Panic where the reference panics (modulus <= 1)."""
+        out = ctypes.c_void_p()
+        rc = getattr(lib(), "cntt_prime%d_plan_new" % cls.BITS)(polynomial_size, modulus, ctypes.byref(out))
+        if rc == _lib.NONE:
+            return None
+        check(rc)
+        return cls(out.value)
+
+    def clone(self):
+        return type(self)(getattr(lib(), self._p + "plan_clone")(self._h))
+
+    def __del__(self):
+        try:
+            if self._owned and self._h:
+                getattr(lib(), self._p + "plan_free")(self._h)
+        except Exception:
+            pass
+
+    def __repr__(self):  # Debug prints only ntt_size and modulus: src/prime64.rs:238-245
+        return "Plan { ntt_size: %d, modulus: %d }" % (self.ntt_size(), self.modulus())
+
+    # -- accessors ---------------------------------------------------------------------------
+    def ntt_size(self):
+        return self._n
+
+    def modulus(self):
+        return getattr(lib(), self._p + "modulus")(self._h)
+
+    def info(self):
+        out = _lib.PlanInfo()
+        check(getattr(lib(), self._p + "plan_info")(self._h, ctypes.byref(out)))
+        return out
+
+    def table(self, which):
+        out = np.zeros(self._n, dtype=self.dtype)
+        rc = getattr(lib(), self._p + "plan_table")(self._h, which, out.ctypes.data, out.size)
+        if rc == _lib.NONE:
+            return None
+        check(rc)
+        return out
+
+    @property
+    def dtype(self):
+        return np.uint64 if self.BITS == 64 else np.uint32
+
+    def _arg(self, buf):
+        ptr, count, esz, where, stream = buffer_info(buf)
+        if esz != self.BITS // 8:
+            raise TypeError("expected %d-byte elements" % (self.BITS // 8))
+        return ptr, count, where, stream
+
+    # -- the reference's slice API (host memory, one polynomial) -------------------------------
+    def fwd(self, buf):
+        ptr, count, where, _ = self._arg(buf)
+        if where != _lib.MEM_HOST:
+            raise TypeError("fwd() takes a host slice; use fwd_batch() for device tensors")
+        check(getattr(lib(), self._p + "fwd")(self._h, ptr, count))
+
+    def inv(self, buf):
+        ptr, count, where, _ = self._arg(buf)
+        if where != _lib.MEM_HOST:
+            raise TypeError("inv() takes a host slice; use inv_batch() for device tensors")
+        check(getattr(lib(), self._p + "inv")(self._h, ptr, count))
+
+    def mul_assign_normalize(self, lhs, rhs):
+        lp, lc, _, _ = self._arg(lhs)
+        rp, rc_, _, _ = self._arg(rhs)
+        check(getattr(lib(), self._p + "mul_assign_normalize")(self._h, lp, lc, rp, rc_))
+
+    def normalize(self, values):
+        vp, vc, _, _ = self._arg(values)
+        check(getattr(lib(), self._p + "normalize")(self._h, vp, vc))
+
+    def mul_accumulate(self, acc, lhs, rhs):
+        ap, ac, _, _ = self._arg(acc)
+        lp, lc, _, _ = self._arg(lhs)
+        rp, rc_, _, _ = self._arg(rhs)
+        check(getattr(lib(), self._p + "mul_accumulate")(self._h, ap, ac, lp, lc, rp, rc_))
+
+    # -- batched API: `batch` polynomials back to back, host arrays or device tensors ----------
+    def _batch(self, buf):
+        ptr, count, where, stream = self._arg(buf)
+        if count % self._n:
+            raise Panic("buffer length %d is not a multiple of ntt_size %d" % (count, self._n))
+        return ptr, count // self._n, where, stream
+
+    def fwd_batch(self, bufs):
+        ptr, batch, where, stream = self._batch(bufs)
+        check(getattr(lib(), self._p + "fwd_batch")(self._h, ptr, batch, where, stream))
+
+    def inv_batch(self, bufs):
+        ptr, batch, where, stream = self._batch(bufs)
+        check(getattr(lib(), self._p + "inv_batch")(self._h, ptr, batch, where, stream))
+
+    def mul_assign_normalize_batch(self, lhs, rhs):
+        lp, batch, where, stream = self._batch(lhs)
+        rp, rb, rwhere, _ = self._batch(rhs)
+        if rb != batch or rwhere != where:
+            raise Panic("lhs and rhs must have the same shape and live in the same memory")
+        check(getattr(lib(), self._p + "mul_assign_normalize_batch")(self._h, lp, rp, batch, where, stream))
+
+    def normalize_batch(self, values):
+        vp, batch, where, stream = self._batch(values)
+        check(getattr(lib(), self._p + "normalize_batch")(self._h, vp, batch, where, stream))
+
+    def mul_accumulate_batch(self, acc, lhs, rhs):
+        ap, batch, where, stream = self._batch(acc)
+        lp, lb, lw, _ = self._batch(lhs)
+        rp, rb, rw, _ = self._batch(rhs)
+        if lb != batch or rb != batch or lw != where or rw != where:
+            raise Panic("acc, lhs and rhs must have the same shape and live in the same memory")
+        check(getattr(lib(), self._p + "mul_accumulate_batch")(self._h, ap, lp, rp, batch, where, stream))
+
+    def time_batch(self, op, bufs, rhs=None, reps=1):
+        """HIP-event time (ms) of `reps` back-to-back launches on the tensor's stream.
+        op: 0 fwd, 1 inv, 2 mul_assign_normalize."""
+        ptr, batch, where, stream = self._batch(bufs)
+        if where != _lib.MEM_DEVICE:
+            raise TypeError("time_batch needs device memory")
+        rp = self._batch(rhs)[0] if rhs is not None else None
+        ms = ctypes.c_float(0)
+        check(getattr(lib(), self._p + "time_batch")(self._h, op, ptr, rp, batch, reps, stream, ctypes.byref(ms)))
+        return ms.value

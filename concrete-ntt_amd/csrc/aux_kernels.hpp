@@ -1,0 +1,279 @@
+// Elementwise kernels around the transforms: pointwise products, residue split, CRT
+// recombination, synthetic-input fill, and the strided global stages used when a polynomial does
+// not fit one workgroup's LDS.  All are HBM-streaming kernels: 16-byte accesses per lane,
+// grid-stride loops capped at a few waves per SIMD.
+#pragma once
+#include "ntt_arith.hpp"
+
+namespace cntt {
+
+// ---------------------------------------------------------------------------------------------
+// K3/K4: pointwise kernels.  src/prime64.rs:534-584,690-699 ; src/prime32.rs:383-408,477-488,575-598
+// (values equal the reference's Barrett-then-Shoup results: canonical a*b*N^-1, a*N^-1, acc+a*b)
+// ---------------------------------------------------------------------------------------------
+enum : int { PW_MUL_NORMALIZE = 0, PW_NORMALIZE = 1, PW_MUL_ACCUMULATE = 2 };
+
+template <class T, int OP>
+__global__ __launch_bounds__(256) void pointwise_kernel(T *__restrict__ a, const T *__restrict__ b,
+                                                        const T *__restrict__ c, const ModParams<T> P, size_t count) {
+    // OP == MUL_NORMALIZE: a <- a*b*ninv ; NORMALIZE: a <- a*ninv ; MUL_ACCUMULATE: a <- a + b*c
+    constexpr int NV = 16 / sizeof(T);
+    using V = __attribute__((ext_vector_type(NV))) T;
+    const bool generic = P.cls == CLS_GENERIC;
+    const size_t nvec = count / NV;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+        V va = reinterpret_cast<const V *>(a)[i];
+        V vb, vc;
+        if constexpr (OP != PW_NORMALIZE) vb = reinterpret_cast<const V *>(b)[i];
+        if constexpr (OP == PW_MUL_ACCUMULATE) vc = reinterpret_cast<const V *>(c)[i];
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            if constexpr (OP == PW_MUL_NORMALIZE) va[k] = mul_normalize<T>(va[k], vb[k], P, generic);
+            if constexpr (OP == PW_NORMALIZE) va[k] = normalize1<T>(va[k], P, generic);
+            if constexpr (OP == PW_MUL_ACCUMULATE) va[k] = mul_acc<T>(va[k], vb[k], vc[k], P, generic);
+        }
+        reinterpret_cast<V *>(a)[i] = va;
+    }
+    // tail (count not a multiple of the vector width)
+    for (size_t i = nvec * NV + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        if constexpr (OP == PW_MUL_NORMALIZE) a[i] = mul_normalize<T>(a[i], b[i], P, generic);
+        if constexpr (OP == PW_NORMALIZE) a[i] = normalize1<T>(a[i], P, generic);
+        if constexpr (OP == PW_MUL_ACCUMULATE) a[i] = mul_acc<T>(a[i], b[i], c[i], P, generic);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// synthetic inputs: element i = mulhi(splitmix64(seed + i), bound)   (bound == 0: raw)
+// (same definition as oracle/cntt_oracle.c orc_fill_uniform_*)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+template <class T> __global__ __launch_bounds__(256) void fill_uniform_kernel(T *dst, size_t count, T bound, uint64_t seed) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        const uint64_t r = splitmix64(seed + i);
+        if constexpr (sizeof(T) == 8)
+            dst[i] = bound ? mulhi((uint64_t)r, (uint64_t)bound) : r;
+        else
+            dst[i] = bound ? (uint32_t)(((r >> 32) * (uint64_t)bound) >> 32) : (uint32_t)(r >> 32);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// strided global stage: one radix-2 stage over whole polynomials in HBM, used for the top
+// `depth` stages of transforms larger than one workgroup's LDS (the reference's depth-first
+// recursion step, src/prime64/shoup.rs:660-682 / :1444-1466).
+// ---------------------------------------------------------------------------------------------
+template <class T, bool INV, int CLS>
+__global__ __launch_bounds__(256) void global_stage_kernel(T *__restrict__ data, const TwPair<T> *__restrict__ tw,
+                                                           const ModParams<T> P, uint32_t logn, uint32_t s,
+                                                           size_t nbfly_total, bool finish) {
+    // butterfly i of polynomial q: block = i / t, j = i % t, t = N >> (s+1)
+    const uint32_t logt = logn - 1 - s;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t gi = (size_t)blockIdx.x * blockDim.x + threadIdx.x; gi < nbfly_total; gi += stride) {
+        const size_t q = gi >> (logn - 1);
+        const uint32_t i = (uint32_t)(gi & (((size_t)1 << (logn - 1)) - 1));
+        const uint32_t blk = i >> logt, j = i & ((1u << logt) - 1u);
+        T *x = data + (q << logn) + ((size_t)blk << (logt + 1)) + j;
+        T *y = x + ((size_t)1 << logt);
+        const TwPair<T> w = tw[(1u << s) + blk];
+        T a = *x, b = *y;
+        if constexpr (INV) {
+            Bfly<T, CLS>::inv(a, b, w.w, w.ws, P);
+            if (finish) {
+                a = Bfly<T, CLS>::finish_inv(a, P);
+                b = Bfly<T, CLS>::finish_inv(b, P);
+            }
+        } else {
+            Bfly<T, CLS>::fwd(a, b, w.w, w.ws, P);
+        }
+        *x = a;
+        *y = b;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K5: residue split.  value % P_i for each prime (src/native64.rs:980-993 etc.), or plain
+// truncation for the binary operand (src/native_binary64.rs:379-385).
+// Layout: value[batch*N] words; residues[k] -> batch*N elements of R.
+// ---------------------------------------------------------------------------------------------
+struct SplitArgs {
+    void *res[10];
+    uint64_t prime[10];
+    // Lemire-style reciprocal floor(2^64 / p) + 1 for p < 2^32 operands is not needed: we use
+    // exact 64-bit `%` on the 32-bit primes via two-step reduction (see split_mod32).
+    int k;
+};
+
+// x mod p for a 30-bit prime p, x < 2^64: hi word first, both steps exact in 64-bit arithmetic
+__device__ __forceinline__ uint32_t mod_u64_p32(uint64_t x, uint32_t p) { return (uint32_t)(x % p); }
+
+template <class W, class R, bool BINARY>
+__global__ __launch_bounds__(256) void split_kernel(const W *__restrict__ value, SplitArgs A, size_t count) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        if constexpr (sizeof(W) == 16) {
+            // u128 as 16-byte little-endian (lo, hi)
+            const uint64_t lo = reinterpret_cast<const uint64_t *>(value)[2 * i];
+            const uint64_t hi = reinterpret_cast<const uint64_t *>(value)[2 * i + 1];
+#pragma unroll 1
+            for (int k = 0; k < A.k; ++k) {
+                R r;
+                if constexpr (BINARY) {
+                    r = (R)lo;
+                } else {
+                    const uint64_t p = A.prime[k];
+                    // (hi * 2^64 + lo) mod p with p < 2^32: reduce hi, then fold 32 bits at a time
+                    uint64_t acc = hi % p;
+                    acc = ((acc << 32) | (lo >> 32)) % p;
+                    acc = ((acc << 32) | (lo & 0xffffffffull)) % p;
+                    r = (R)acc;
+                }
+                reinterpret_cast<R *>(A.res[k])[i] = r;
+            }
+        } else {
+            const W v = value[i];
+#pragma unroll 1
+            for (int k = 0; k < A.k; ++k) {
+                R r;
+                if constexpr (BINARY)
+                    r = (R)v;
+                else
+                    r = (R)((uint64_t)v % A.prime[k]);
+                reinterpret_cast<R *>(A.res[k])[i] = r;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K6: CRT recombination (mixed radix / Garner, centred lift decided by the TOP digit, wrapping)
+//   src/native32.rs:28-56, src/native64.rs:91-141, src/native128.rs:20-118,
+//   src/native_binary32.rs:22-41, src/native_binary64.rs:33-61, src/native_binary128.rs:13-63,
+//   52-bit: src/native32.rs:223-253, src/native64.rs:770-829, src/native_binary32.rs:111-125,
+//           src/native_binary64.rs:230-260
+// The digit recurrence is generic over "groups": digit g has modulus M[g] (one prime or a product
+// of two primes, < 2^62), residue r_g (combined inside a pair group first), and
+//   v_g = (r_g - (v_0 + M_0 (v_1 + M_1 (...)))) * inv_g  mod M_g ,  inv_g = (M_0 ... M_{g-1})^-1 mod M_g
+// The digits are unique in [0, M_g), so they equal the reference's v0, v12, v34, ... whatever
+// product formula computes them.  All constants are computed on the host (exact) and passed by value.
+// ---------------------------------------------------------------------------------------------
+struct CrtArgs {
+    const void *res[10];
+    int k;              // residue arrays
+    int ngroups;        // number of digits
+    int ga[5], gb[5];   // prime indices of each group; gb < 0: the group is the single prime ga
+    uint64_t prime[10];
+    uint64_t pair_inv[5];        // pair groups: P_a^-1 mod P_b
+    uint64_t M[5];               // group moduli (a prime or a product of two 30-bit primes, < 2^62)
+    uint64_t inv[5];             // inv[g] = (M_0..M_{g-1})^-1 mod M[g]  (inv[0] unused)
+    uint64_t inv_shoup[5];       // floor(inv[g] * 2^64 / M[g])
+    uint64_t Mmod[5][5];         // Mmod[g][h] = M[h] mod M[g]            (h < g)
+    uint64_t Mmod_shoup[5][5];   // Shoup companions
+    uint64_t prefix_lo[6], prefix_hi[6];  // prefix[g] = M_0 ... M_{g-1} mod 2^128 (prefix[ngroups] = full product)
+};
+
+// a * b mod m via Shoup (b < m < 2^63, a < 2^64): canonical
+__device__ __forceinline__ uint64_t shoup_mulmod(uint64_t a, uint64_t b, uint64_t b_shoup, uint64_t m) {
+    const uint64_t q = mulhi(a, b_shoup);
+    const uint64_t r = a * b - q * m;
+    return r >= m ? r - m : r;
+}
+
+struct u128d {
+    uint64_t lo, hi;
+};
+__device__ __forceinline__ u128d mul_64x128(uint64_t a, uint64_t blo, uint64_t bhi) {  // a * b mod 2^128
+    u128d r;
+    r.lo = a * blo;
+    r.hi = mulhi(a, blo) + a * bhi;
+    return r;
+}
+__device__ __forceinline__ u128d add128(u128d a, u128d b) {
+    u128d r;
+    r.lo = a.lo + b.lo;
+    r.hi = a.hi + b.hi + (r.lo < a.lo ? 1u : 0u);
+    return r;
+}
+__device__ __forceinline__ u128d sub128(u128d a, u128d b) {
+    u128d r;
+    r.lo = a.lo - b.lo;
+    r.hi = a.hi - b.hi - (a.lo < b.lo ? 1u : 0u);
+    return r;
+}
+
+template <class W, class R>
+__global__ __launch_bounds__(256) void crt_kernel(W *__restrict__ value, CrtArgs A, size_t count) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        uint64_t rg[5];
+#pragma unroll
+        for (int g = 0; g < 5; ++g) {
+            if (g < A.ngroups) {
+                const uint64_t va = reinterpret_cast<const R *>(A.res[A.ga[g]])[i];
+                if (A.gb[g] >= 0) {
+                    // v_b = (m_b - v_a) * P_a^-1 mod P_b ; group residue = v_a + v_b * P_a  (src/native64.rs:98-107)
+                    const uint64_t pa = A.prime[A.ga[g]], pb = A.prime[A.gb[g]];
+                    const uint64_t mb = reinterpret_cast<const R *>(A.res[A.gb[g]])[i];
+                    const uint64_t d = (2 * pb + mb - va) % pb;
+                    const uint64_t vb = (d * A.pair_inv[g]) % pb;  // 30-bit operands: exact in 64 bits
+                    rg[g] = va + vb * pa;
+                } else {
+                    rg[g] = va;
+                }
+            }
+        }
+        // digits
+        uint64_t v[5];
+        v[0] = rg[0];
+#pragma unroll
+        for (int g = 1; g < 5; ++g) {
+            if (g < A.ngroups) {
+                const uint64_t m = A.M[g];
+                // acc = (v_0 + M_0 (v_1 + M_1 (... v_{g-1}))) mod M[g], Horner from the top digit
+                uint64_t acc = v[g - 1];
+                if (acc >= m) acc %= m;
+#pragma unroll
+                for (int h = g - 2; h >= 0; --h) {
+                    uint64_t t = shoup_mulmod(acc, A.Mmod[g][h], A.Mmod_shoup[g][h], m);
+                    uint64_t vh = v[h];
+                    if (vh >= m) vh %= m;
+                    t += vh;
+                    acc = t >= m ? t - m : t;
+                }
+                uint64_t rr = rg[g];
+                if (rr >= m) rr %= m;
+                const uint64_t d = rr >= acc ? rr - acc : rr + m - acc;
+                v[g] = shoup_mulmod(d, A.inv[g], A.inv_shoup[g], m);
+            }
+        }
+        uint64_t vtop = v[0], mtop = A.M[0];
+#pragma unroll
+        for (int g = 1; g < 5; ++g)
+            if (g == A.ngroups - 1) {
+                vtop = v[g];
+                mtop = A.M[g];
+            }
+        const bool sign = vtop > (mtop / 2);
+        u128d pos = {v[0], 0};
+#pragma unroll
+        for (int g = 1; g < 5; ++g)
+            if (g < A.ngroups) pos = add128(pos, mul_64x128(v[g], A.prefix_lo[g], A.prefix_hi[g]));
+        const u128d full = {A.prefix_lo[A.ngroups], A.prefix_hi[A.ngroups]};
+        const u128d out = sign ? sub128(pos, full) : pos;
+        if constexpr (sizeof(W) == 16) {
+            reinterpret_cast<uint64_t *>(value)[2 * i] = out.lo;
+            reinterpret_cast<uint64_t *>(value)[2 * i + 1] = out.hi;
+        } else {
+            value[i] = (W)out.lo;
+        }
+    }
+}
+
+}  // namespace cntt

@@ -1,0 +1,316 @@
+#!/usr/bin/env python3
+"""Pass schedules of the LDS-resident NTT kernels (single source of truth).
+
+A transform of N = 2^LOGN points is executed by TPP = N / E threads (E = 2^LOGE coefficients per
+thread) as a short list of *passes*.  In a pass every thread holds the E coefficients whose index
+bits listed in RMASK vary (the other LOGN-LOGE index bits are the thread's id inside the
+polynomial), and performs the butterfly stages whose index bit is in GMASK (a subset of RMASK)
+entirely in registers.  Between passes the polynomial is exchanged through LDS.  The first pass
+reads global memory and the last pass writes it directly, so RMASK of the first/last pass decides
+how well those accesses coalesce.
+
+Stage <-> index bit: the forward (Cooley-Tukey, src/prime64/shoup.rs:544-615) stage s pairs
+coefficients that differ in bit b = LOGN-1-s and runs s = 0..LOGN-1 (b descending); the inverse
+(Gentleman-Sande, src/prime64/shoup.rs:1306-1377) visits the same bits ascending.  In both, the
+butterfly of element e on bit b uses table entry (1 << (LOGN-1-b)) + (e >> (b+1)).
+
+This file emits sched_gen.inc (C++ specialisations) and, with --check, replays every schedule in
+pure Python against a direct evaluation of the transform, so the index logic is validated without
+a GPU.  It also scores LDS bank conflicts of each exchange for a candidate XOR swizzle using the
+per-instruction lane groups of MI355X_MICROARCH.md (LDS section).
+"""
+import argparse
+import itertools
+import os
+import random
+import sys
+
+MAX_LDS_BYTES = 128 * 1024  # one polynomial per workgroup must fit (160 KiB LDS per CU)
+
+
+def bits_of(mask):
+    return [b for b in range(32) if (mask >> b) & 1]
+
+
+def pdep(x, mask):
+    out, k = 0, 0
+    for b in bits_of(mask):
+        out |= ((x >> k) & 1) << b
+        k += 1
+    return out
+
+
+class Sched:
+    def __init__(self, bits, logn, inv, loge, passes, swz, block):
+        self.bits, self.logn, self.inv, self.loge = bits, logn, inv, loge
+        self.passes = passes  # list of (rmask, gmask)
+        self.swz = swz        # list of (shift, mask, lshift) XOR terms applied to the element index
+        self.tpp = 1 << (logn - loge)
+        self.block = block
+        self.ppb = max(1, block // self.tpp)
+
+    def phys(self, e):
+        out = e
+        for sh, m, l in self.swz:
+            out ^= ((e >> sh) & m) << l
+        return out
+
+
+def default_loge(bits, logn):
+    loge = 4
+    while (1 << (logn - loge)) > 1024:
+        loge += 1
+    return min(loge, logn)
+
+
+def make_passes(bits, logn, inv, loge, first_x=None):
+    """Forward pass list (top bits first); the inverse is its mirror."""
+    full = (1 << logn) - 1
+    if logn <= loge:
+        return [(full, full)]
+    v = {64: 1, 32: 2}[bits]
+    npass = -(-logn // loge)
+    slack = npass * loge - logn
+    if first_x is None:
+        first_x = min(v, slack)
+    passes = []
+    hi = logn  # exclusive upper bit of the not-yet-done stage bits
+    for k in range(npass):
+        if k == 0:
+            g = loge - first_x
+            gm = ((1 << g) - 1) << (hi - g)
+            rm = gm | ((1 << first_x) - 1)
+        elif k == npass - 1:
+            g = hi
+            gm = (1 << g) - 1
+            x = loge - g
+            rm = gm | (((1 << x) - 1) << (logn - x))
+        else:
+            g = loge
+            gm = ((1 << g) - 1) << (hi - g)
+            rm = gm
+        assert bin(rm).count("1") == loge and g > 0, (bits, logn, k, bin(rm))
+        passes.append((rm, gm))
+        hi -= g
+    assert hi == 0
+    return passes[::-1] if inv else passes
+
+
+# hand-tuned overrides: (bits, logn, inv) -> dict(first_x=.., swz=[..], block=..)
+OVERRIDES = {
+}
+
+
+def default_swz(bits, logn, loge, passes):
+    """XOR the thread-id bits that sit above bit 6 into bits [2..5): decorrelates the strided
+    exchange reads (see score())."""
+    if logn <= 6:
+        return []
+    terms = []
+    hi_bits = min(3, logn - 6)
+    terms.append((6, (1 << hi_bits) - 1, 2))
+    return terms
+
+
+def make_sched(bits, logn, inv):
+    ov = OVERRIDES.get((bits, logn, inv), {})
+    loge = ov.get("loge", default_loge(bits, logn))
+    passes = ov.get("passes") or make_passes(bits, logn, inv, loge, ov.get("first_x"))
+    swz = ov.get("swz", default_swz(bits, logn, loge, passes))
+    tpp = 1 << (logn - loge)
+    block = ov.get("block", max(tpp, 256 if tpp <= 256 else tpp))
+    return Sched(bits, logn, inv, loge, passes, swz, block)
+
+
+def supported(bits, logn):
+    lo = 4 if bits == 64 else 5  # try_new gates: src/prime64.rs:709, src/prime32.rs:635
+    return lo <= logn and (1 << logn) * (bits // 8) <= MAX_LDS_BYTES
+
+
+# --------------------------------------------------------------------------------------------
+# pure-Python replay (exact arithmetic) -- validates the schedule/index logic
+# --------------------------------------------------------------------------------------------
+def replay(s, a, p, table):
+    """table[i]: twid (fwd) or inv_twid (inv), laid out as the reference."""
+    n = 1 << s.logn
+    data = list(a)
+    for (rm, gm) in s.passes:
+        cm = ((1 << s.logn) - 1) & ~rm
+        new = list(data)
+        for tid in range(s.tpp):
+            ebase = pdep(tid, cm)
+            E = 1 << s.loge
+            regs = [data[ebase | pdep(j, rm)] for j in range(E)]
+            gbits = bits_of(gm)
+            order = gbits if s.inv else gbits[::-1]
+            rbits = bits_of(rm)
+            for b in order:
+                k = rbits.index(b)
+                for j in range(E):
+                    if (j >> k) & 1:
+                        continue
+                    j1 = j | (1 << k)
+                    e = ebase | pdep(j, rm)
+                    w = table[(1 << (s.logn - 1 - b)) + (e >> (b + 1))]
+                    x, y = regs[j], regs[j1]
+                    if s.inv:
+                        regs[j], regs[j1] = (x + y) % p, (x - y) * w % p
+                    else:
+                        t = y * w % p
+                        regs[j], regs[j1] = (x + t) % p, (x - t) % p
+            for j in range(E):
+                new[ebase | pdep(j, rm)] = regs[j]
+        data = new
+    return data
+
+
+def direct(logn, inv, a, p, table):
+    n = 1 << logn
+    a = list(a)
+    if not inv:
+        t, m = n, 1
+        while m < n:
+            t //= 2
+            for i in range(m):
+                w = table[m + i]
+                for j in range(2 * i * t, 2 * i * t + t):
+                    u, v = a[j], a[j + t] * w % p
+                    a[j], a[j + t] = (u + v) % p, (u - v) % p
+            m *= 2
+    else:
+        t, m = 1, n
+        while m > 1:
+            m //= 2
+            for i in range(m):
+                w = table[m + i]
+                for j in range(2 * i * t, 2 * i * t + t):
+                    u, v = a[j], a[j + t]
+                    a[j], a[j + t] = (u + v) % p, (u - v) * w % p
+            t *= 2
+    return a
+
+
+# --------------------------------------------------------------------------------------------
+# LDS bank-conflict score of an exchange (MI355X_MICROARCH.md, LDS table)
+# --------------------------------------------------------------------------------------------
+B128_GROUPS = [
+    list(range(0, 4)) + list(range(12, 16)) + list(range(20, 28)),
+    list(range(4, 12)) + list(range(16, 20)) + list(range(28, 32)),
+    list(range(32, 36)) + list(range(44, 48)) + list(range(52, 60)),
+    list(range(36, 44)) + list(range(48, 52)) + list(range(60, 64)),
+]
+
+
+def lane_groups(kind, nbytes):
+    if kind == "read":
+        if nbytes <= 8:
+            return [list(range(0, 32)), list(range(32, 64))], (32 if nbytes == 4 else 64)
+        return B128_GROUPS, 64
+    if nbytes == 4:
+        return [list(range(0, 32)), list(range(32, 64))], 32
+    if nbytes == 8:
+        return [list(range(16 * i, 16 * i + 16)) for i in range(4)], 32
+    return [list(range(8 * i, 8 * i + 8)) for i in range(8)], 32
+
+
+def vec_bits(rm, bits):
+    v, cap = 0, {64: 1, 32: 2}[bits]
+    while v < cap and (rm >> v) & 1:
+        v += 1
+    return v
+
+
+def score(s, rm, kind):
+    """Average LDS cycles per wave-instruction relative to conflict-free (1.0 = clean)."""
+    cm = ((1 << s.logn) - 1) & ~rm
+    v = vec_bits(rm, s.bits)
+    nbytes = (s.bits // 8) << v
+    groups, nbanks = lane_groups(kind, nbytes)
+    tot, cnt = 0.0, 0
+    E = 1 << s.loge
+    wave_tids = min(64, s.tpp)
+    for j in range(0, E, 1 << v):
+        for grp in groups:
+            per_bank = {}
+            for lane in grp:
+                tid = lane % wave_tids  # several polynomials per wave: separate LDS regions, same pattern
+                poly = lane // wave_tids
+                e = pdep(tid, cm) | pdep(j, rm)
+                addr = (s.phys(e) + poly * (1 << s.logn)) * (s.bits // 8)
+                for d in range(nbytes // 4):
+                    bank = ((addr // 4) + d) % nbanks
+                    per_bank.setdefault(bank, set()).add((addr // 4) + d)
+            worst = max(len(x) for x in per_bank.values())
+            tot += worst
+            cnt += 1
+    return tot / cnt
+
+
+def report(s):
+    out = []
+    for k in range(len(s.passes) - 1):
+        w = score(s, s.passes[k][0], "write")
+        r = score(s, s.passes[k + 1][0], "read")
+        out.append((w, r))
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+def emit(path):
+    lines = ["// GENERATED by gen_sched.py -- do not edit; re-run `python3 gen_sched.py`.",
+             "// Sched<BITS, LOGN, INV>: pass masks and LDS swizzle of the LDS-resident NTT kernels.", ""]
+    for bits in (64, 32):
+        for logn in range(4, 16):
+            if not supported(bits, logn):
+                continue
+            for inv in (False, True):
+                s = make_sched(bits, logn, inv)
+                np_ = len(s.passes)
+                swz = list(s.swz) + [(0, 0, 0)] * (2 - len(s.swz))
+                lines.append("template <> struct Sched<%d, %d, %s> {" % (bits, logn, "true" if inv else "false"))
+                lines.append("    static constexpr int LOGE = %d, NPASS = %d, BLOCK = %d;" % (s.loge, np_, s.block))
+                lines.append("    static constexpr uint32_t RMASK[%d] = {%s};" %
+                             (np_, ", ".join("0x%xu" % r for r, _ in s.passes)))
+                lines.append("    static constexpr uint32_t GMASK[%d] = {%s};" %
+                             (np_, ", ".join("0x%xu" % g for _, g in s.passes)))
+                lines.append("    static constexpr uint32_t SWZ_SH0 = %d, SWZ_M0 = 0x%xu, SWZ_L0 = %d;" % swz[0])
+                lines.append("    static constexpr uint32_t SWZ_SH1 = %d, SWZ_M1 = 0x%xu, SWZ_L1 = %d;" % swz[1])
+                lines.append("};")
+    lines.append("")
+    with open(path, "w") as f:
+        f.write("\n".join(lines))
+
+
+def check():
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tests", "golden"))
+    import gen_golden as gg
+    rnd = random.Random(1)
+    for bits, p in ((64, 4611686018427322369), (32, 1062862849)):
+        for logn in range(4, 16):
+            if not supported(bits, logn):
+                continue
+            n = 1 << logn
+            if n > 4096 and logn not in (14, 15):
+                pass
+            pl = gg.Plan(n, p, bits)
+            a = [rnd.randrange(p) for _ in range(n)]
+            for inv in (False, True):
+                s = make_sched(bits, logn, inv)
+                table = pl.inv_twid if inv else pl.twid
+                got = replay(s, a, p, table)
+                want = direct(logn, inv, a, p, table)
+                assert got == want, (bits, logn, inv)
+                print("ok bits=%d logn=%2d inv=%d loge=%d tpp=%4d block=%4d passes=%s lds(w,r)=%s" % (
+                    bits, logn, inv, s.loge, s.tpp, s.block,
+                    ["%x/%x" % (r, g) for r, g in s.passes],
+                    ["%.1f/%.1f" % wr for wr in report(s)]))
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--check", action="store_true")
+    args = ap.parse_args()
+    here = os.path.dirname(os.path.abspath(__file__))
+    emit(os.path.join(here, "sched_gen.inc"))
+    if args.check:
+        check()

@@ -1,0 +1,811 @@
+// libcntt_hip.so host side: plans, device tables, launch logic and the C ABI of include/cntt.h.
+// There is no CPU compute path in this library: every transform runs in the HIP kernels, and every
+// entry point that needs a GPU fails with CNTT_EDEVICE when none is present.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/cntt.h"
+#include "aux_kernels.hpp"
+#include "host_math.hpp"
+#include "ntt_launch.hpp"
+
+using namespace cntt;
+using host::u128;
+
+// ---------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail(CNTT_EDEVICE, "%s: %s", #expr, hipGetErrorString(e_));    \
+    } while (0)
+
+extern "C" const char *cntt_last_error(void) { return g_err.c_str(); }
+extern "C" const char *cntt_version(void) { return "cntt-hip 0.1 (gfx950)"; }
+extern "C" int cntt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+static inline unsigned ew_grid(size_t work_items) {
+    const size_t blocks = (work_items + 255) / 256;
+    return (unsigned)std::max<size_t>(1, std::min<size_t>(blocks, 256 * 8));
+}
+
+// ---------------------------------------------------------------------------------------------
+// prime plans
+// ---------------------------------------------------------------------------------------------
+template <class T> struct DeviceTables {
+    TwPair<T> *fwd = nullptr, *inv = nullptr;
+};
+
+template <class T> struct DeviceCache {
+    std::mutex mu;
+    std::map<int, DeviceTables<T>> per_device;
+    ~DeviceCache() {
+        for (auto &kv : per_device) {
+            int cur = 0;
+            if (hipGetDevice(&cur) != hipSuccess) continue;
+            (void)hipSetDevice(kv.first);
+            (void)hipFree(kv.second.fwd);
+            (void)hipFree(kv.second.inv);
+            (void)hipSetDevice(cur);
+        }
+    }
+};
+
+template <class T> struct PrimePlan {
+    static constexpr int B = sizeof(T) * 8;
+    size_t n = 0;
+    int logn = 0;
+    T p = 0;
+    uint64_t root = 0;
+    bool has_shoup = false;
+    // reference-layout tables (src/prime64.rs:221-236)
+    std::vector<T> twid, twid_shoup, inv_twid, inv_twid_shoup;
+    T p_barrett = 0, n_inv = 0, n_inv_shoup = 0;
+    uint32_t big_q = 0;
+    ModParams<T> mp{};
+    std::shared_ptr<DeviceCache<T>> cache;
+};
+
+struct cntt_plan64 : PrimePlan<uint64_t> {};
+struct cntt_plan32 : PrimePlan<uint32_t> {};
+
+template <class T> static T shoup_of(T x, T p) { return (T)((((u128)x) << (sizeof(T) * 8)) / p); }
+
+// Plan::try_new  (src/prime64.rs:704-771, src/prime32.rs:630-686)
+template <class T, class PlanT> static int plan_new(size_t n, T p, PlanT **out) {
+    constexpr int B = sizeof(T) * 8;
+    if (!out) return fail(CNTT_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (p <= 1) return fail(CNTT_EINVAL, "modulus <= 1: the reference panics in Div%d::new (src/fastdiv.rs)", B);
+    const size_t min_n = (B == 64) ? 16 : 32;
+    if (n < min_n || (n & (n - 1)) != 0) return fail(CNTT_NONE, "polynomial_size must be a power of two >= %zu", min_n);
+    if (n > ((size_t)1 << 30)) return fail(CNTT_NONE, "polynomial_size too large");
+    if (!host::is_prime((uint64_t)p)) return fail(CNTT_NONE, "modulus is not prime");
+    uint64_t w = 0;
+    if (!host::primitive_root((uint64_t)p, 2 * (uint64_t)n, &w))
+        return fail(CNTT_NONE, "no primitive 2n-th root of unity modulo the modulus");
+
+    PlanT *pl = new (std::nothrow) PlanT();
+    if (!pl) return fail(CNTT_ENOMEM, "out of memory");
+    pl->n = n;
+    pl->p = p;
+    pl->root = w;
+    while (((size_t)1 << pl->logn) < n) ++pl->logn;
+    pl->has_shoup = (uint64_t)p < ((uint64_t)1 << (B - 1));
+    pl->twid.assign(n, 0);
+    pl->inv_twid.assign(n, 0);
+    if (pl->has_shoup) {
+        pl->twid_shoup.assign(n, 0);
+        pl->inv_twid_shoup.assign(n, 0);
+    }
+    // twid[bitrev(k)] = w^k ; inv_twid[bitrev((n-k) mod n)] = (k == 0 ? 1 : p - w^k)
+    uint64_t wk = 1;
+    for (size_t k = 0; k < n; ++k) {
+        const size_t fi = host::bit_reverse((uint32_t)pl->logn, (uint32_t)k);
+        const size_t ii = host::bit_reverse((uint32_t)pl->logn, (uint32_t)((n - k) % n));
+        const T x = (k == 0) ? (T)wk : (T)(p - (T)wk);
+        pl->twid[fi] = (T)wk;
+        pl->inv_twid[ii] = x;
+        if (pl->has_shoup) {
+            pl->twid_shoup[fi] = shoup_of<T>((T)wk, p);
+            pl->inv_twid_shoup[ii] = shoup_of<T>(x, p);
+        }
+        wk = host::mulmod(wk, w, (uint64_t)p);
+    }
+    pl->n_inv = (T)host::powmod((uint64_t)n % p, (uint64_t)p - 2, (uint64_t)p);
+    pl->n_inv_shoup = shoup_of<T>(pl->n_inv, p);
+    uint32_t ilog = 0;
+    while (ilog + 1 < (uint32_t)B && (((uint64_t)p) >> (ilog + 1)) != 0) ++ilog;
+    pl->big_q = ilog + 1;
+    {
+        const uint32_t big_l = pl->big_q + (B - 1);
+        pl->p_barrett = (T)((((u128)1) << big_l) / p);  // unused garbage when p >= 2^(B-1), as in the reference
+        if (big_l >= 128) pl->p_barrett = 0;
+    }
+    // device-side parameters
+    ModParams<T> &mp = pl->mp;
+    mp.p = p;
+    mp.neg_p = (T)0 - p;
+    mp.two_p = (T)(2 * p);
+    mp.big_q = pl->big_q;
+    mp.p_barrett = pl->p_barrett;
+    const uint64_t p64 = (uint64_t)p;
+    if (p64 < ((uint64_t)1 << (B - 2)))
+        mp.cls = CLS_LAZY;
+    else if (p64 < ((uint64_t)1 << (B - 1)))
+        mp.cls = CLS_STRICT;
+    else
+        mp.cls = CLS_GENERIC;
+    mp.pinv_neg = (T)host::neg_inv_pow2(p64);
+    const u128 R = ((u128)1) << B;
+    const uint64_t r1 = (uint64_t)(R % p64);
+    const uint64_t r2 = host::mulmod(r1, r1, p64);
+    mp.r2 = (T)r2;
+    if (mp.cls == CLS_GENERIC) {
+        mp.n_inv = (T)host::mulmod((uint64_t)pl->n_inv, r2, p64);  // N^-1 * R^2 (see mul_normalize)
+        mp.n_inv_shoup = 0;
+    } else {
+        mp.n_inv = pl->n_inv;
+        mp.n_inv_shoup = pl->n_inv_shoup;
+    }
+    pl->cache = std::make_shared<DeviceCache<T>>();
+    *out = pl;
+    return CNTT_OK;
+}
+
+// per-device table replica, created on first use under the cache mutex
+template <class T> static int device_tables(const PrimePlan<T> *pl, DeviceTables<T> *out) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(pl->cache->mu);
+    auto it = pl->cache->per_device.find(dev);
+    if (it != pl->cache->per_device.end()) {
+        *out = it->second;
+        return CNTT_OK;
+    }
+    const size_t n = pl->n;
+    std::vector<TwPair<T>> f(n), i(n);
+    const uint64_t p64 = (uint64_t)pl->p;
+    const uint64_t r1 = (uint64_t)((((u128)1) << (sizeof(T) * 8)) % p64);
+    for (size_t k = 0; k < n; ++k) {
+        if (pl->mp.cls == CLS_GENERIC) {  // Montgomery form
+            f[k].w = (T)host::mulmod((uint64_t)pl->twid[k], r1, p64);
+            f[k].ws = 0;
+            i[k].w = (T)host::mulmod((uint64_t)pl->inv_twid[k], r1, p64);
+            i[k].ws = 0;
+        } else {
+            f[k].w = pl->twid[k];
+            f[k].ws = pl->twid_shoup[k];
+            i[k].w = pl->inv_twid[k];
+            i[k].ws = pl->inv_twid_shoup[k];
+        }
+    }
+    DeviceTables<T> t;
+    HIP_TRY(hipMalloc((void **)&t.fwd, n * sizeof(TwPair<T>)));
+    if (hipMalloc((void **)&t.inv, n * sizeof(TwPair<T>)) != hipSuccess) {
+        (void)hipFree(t.fwd);
+        return fail(CNTT_ENOMEM, "hipMalloc of the twiddle tables failed");
+    }
+    HIP_TRY(hipMemcpy(t.fwd, f.data(), n * sizeof(TwPair<T>), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(t.inv, i.data(), n * sizeof(TwPair<T>), hipMemcpyHostToDevice));
+    pl->cache->per_device[dev] = t;
+    *out = t;
+    return CNTT_OK;
+}
+
+template <class T, bool INV, int CLS>
+static void launch_global_stage(T *data, const TwPair<T> *tw, const ModParams<T> &P, uint32_t logn, uint32_t s,
+                                size_t nb, bool finish, hipStream_t st) {
+    hipLaunchKernelGGL((global_stage_kernel<T, INV, CLS>), dim3(ew_grid(nb)), dim3(256), 0, st, data, tw, P, logn, s, nb,
+                       finish);
+}
+template <class T, bool INV>
+static void global_stage(T *data, const TwPair<T> *tw, const ModParams<T> &P, uint32_t logn, uint32_t s, size_t nb,
+                         bool finish, hipStream_t st) {
+    switch (P.cls) {
+    case CLS_LAZY: launch_global_stage<T, INV, CLS_LAZY>(data, tw, P, logn, s, nb, finish, st); break;
+    case CLS_STRICT: launch_global_stage<T, INV, CLS_STRICT>(data, tw, P, logn, s, nb, finish, st); break;
+    default: launch_global_stage<T, INV, CLS_GENERIC>(data, tw, P, logn, s, nb, finish, st); break;
+    }
+}
+
+// batched transform on device memory
+template <class T> static int ntt_device(const PrimePlan<T> *pl, T *d, size_t batch, bool inv, hipStream_t st) {
+    if (batch == 0) return CNTT_OK;
+    DeviceTables<T> t;
+    if (int rc = device_tables(pl, &t)) return rc;
+    const int maxl = MaxLdsLogN<T>::value;
+    const int depth = pl->logn > maxl ? pl->logn - maxl : 0;
+    const int sub_logn = pl->logn - depth;
+    if ((batch << depth) >= ((size_t)1 << 32)) return fail(CNTT_EINVAL, "batch too large for one launch");
+    const uint32_t nsub = (uint32_t)(batch << depth);
+    const size_t nbfly = batch * (pl->n / 2);
+    hipError_t e;
+    if (!inv) {
+        for (int s = 0; s < depth; ++s) global_stage<T, false>(d, t.fwd, pl->mp, (uint32_t)pl->logn, (uint32_t)s, nbfly, false, st);
+        e = launch_ntt<T, false>(sub_logn, (int)pl->mp.cls, d, t.fwd, pl->mp, nsub, (uint32_t)depth, st);
+    } else {
+        e = launch_ntt<T, true>(sub_logn, (int)pl->mp.cls, d, t.inv, pl->mp, nsub, (uint32_t)depth, st);
+        for (int s = depth - 1; s >= 0 && e == hipSuccess; --s)
+            global_stage<T, true>(d, t.inv, pl->mp, (uint32_t)pl->logn, (uint32_t)s, nbfly, s == 0, st);
+    }
+    if (e != hipSuccess) return fail(CNTT_EDEVICE, "NTT kernel launch failed: %s", hipGetErrorString(e));
+    HIP_TRY(hipGetLastError());
+    return CNTT_OK;
+}
+
+template <class T, int OP>
+static int pointwise_device(const PrimePlan<T> *pl, T *a, const T *b, const T *c, size_t count, hipStream_t st) {
+    if (count == 0) return CNTT_OK;
+    const size_t nv = count / (16 / sizeof(T)) + 1;
+    hipLaunchKernelGGL((pointwise_kernel<T, OP>), dim3(ew_grid(nv)), dim3(256), 0, st, a, b, c, pl->mp, count);
+    HIP_TRY(hipGetLastError());
+    return CNTT_OK;
+}
+
+// RAII device scratch for host-memory calls
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    int alloc(size_t bytes) {
+        if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) {
+            p = nullptr;
+            return fail(CNTT_EDEVICE, "hipMalloc(%zu) failed (no GPU, or out of device memory)", bytes);
+        }
+        return CNTT_OK;
+    }
+};
+
+// op: 0 fwd, 1 inv, 2 mul_assign_normalize, 3 normalize, 4 mul_accumulate ; count = total elements
+template <class T>
+static int prime_op(const PrimePlan<T> *pl, int op, T *a, const T *b, const T *c, size_t count, size_t batch,
+                    cntt_mem_t where, hipStream_t st) {
+    if (!pl) return fail(CNTT_EINVAL, "plan is NULL");
+    if (count == 0) return CNTT_OK;
+    if (!a || (op == 2 && !b) || (op == 4 && (!b || !c))) return fail(CNTT_EINVAL, "NULL buffer");
+    auto run = [&](T *da, const T *db, const T *dc) -> int {
+        switch (op) {
+        case 0: return ntt_device<T>(pl, da, batch, false, st);
+        case 1: return ntt_device<T>(pl, da, batch, true, st);
+        case 2: return pointwise_device<T, PW_MUL_NORMALIZE>(pl, da, db, nullptr, count, st);
+        case 3: return pointwise_device<T, PW_NORMALIZE>(pl, da, nullptr, nullptr, count, st);
+        default: return pointwise_device<T, PW_MUL_ACCUMULATE>(pl, da, db, dc, count, st);
+        }
+    };
+    if (where == CNTT_MEM_DEVICE) return run(a, b, c);
+    const size_t bytes = count * sizeof(T);
+    DevBuf da, db, dc;
+    if (int rc = da.alloc(bytes)) return rc;
+    HIP_TRY(hipMemcpyAsync(da.p, a, bytes, hipMemcpyHostToDevice, st));
+    if (op == 2 || op == 4) {
+        if (int rc = db.alloc(bytes)) return rc;
+        HIP_TRY(hipMemcpyAsync(db.p, b, bytes, hipMemcpyHostToDevice, st));
+    }
+    if (op == 4) {
+        if (int rc = dc.alloc(bytes)) return rc;
+        HIP_TRY(hipMemcpyAsync(dc.p, c, bytes, hipMemcpyHostToDevice, st));
+    }
+    if (int rc = run((T *)da.p, (const T *)db.p, (const T *)dc.p)) return rc;
+    HIP_TRY(hipMemcpyAsync(a, da.p, bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return CNTT_OK;
+}
+
+template <class T> static int plan_info(const PrimePlan<T> *pl, cntt_plan_info_t *out) {
+    if (!pl || !out) return fail(CNTT_EINVAL, "NULL argument");
+    out->ntt_size = pl->n;
+    out->modulus = pl->p;
+    out->p_barrett = pl->p_barrett;
+    out->big_q = pl->big_q;
+    out->n_inv_mod_p = pl->n_inv;
+    out->n_inv_mod_p_shoup = pl->n_inv_shoup;
+    out->root = pl->root;
+    out->has_shoup = pl->has_shoup ? 1 : 0;
+    out->arith_class = (int32_t)pl->mp.cls;
+    return CNTT_OK;
+}
+template <class T> static int plan_table(const PrimePlan<T> *pl, cntt_table_t which, T *out, size_t len) {
+    if (!pl || !out) return fail(CNTT_EINVAL, "NULL argument");
+    if (len != pl->n) return fail(CNTT_ELEN, "len %zu != ntt_size %zu", len, pl->n);
+    const std::vector<T> *src = nullptr;
+    switch (which) {
+    case CNTT_TWID: src = &pl->twid; break;
+    case CNTT_TWID_SHOUP: src = &pl->twid_shoup; break;
+    case CNTT_INV_TWID: src = &pl->inv_twid; break;
+    case CNTT_INV_TWID_SHOUP: src = &pl->inv_twid_shoup; break;
+    default: return fail(CNTT_EINVAL, "unknown table");
+    }
+    if (src->empty()) return fail(CNTT_NONE, "the plan has no Shoup tables (modulus >= 2^(B-1))");
+    std::memcpy(out, src->data(), len * sizeof(T));
+    return CNTT_OK;
+}
+
+template <class T>
+static int time_batch(const PrimePlan<T> *pl, int op, T *bufs, const T *rhs, size_t batch, int reps, hipStream_t st,
+                      float *ms_out) {
+    if (!pl || !bufs || !ms_out || reps < 1) return fail(CNTT_EINVAL, "bad argument");
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    int rc = CNTT_OK;
+    (void)hipEventRecord(e0, st);
+    for (int r = 0; r < reps && rc == CNTT_OK; ++r)
+        rc = prime_op<T>(pl, op, bufs, rhs, nullptr, batch * pl->n, batch, CNTT_MEM_DEVICE, st);
+    (void)hipEventRecord(e1, st);
+    if (rc == CNTT_OK) {
+        hipError_t e = hipEventSynchronize(e1);
+        if (e == hipSuccess) e = hipEventElapsedTime(ms_out, e0, e1);
+        if (e != hipSuccess) rc = fail(CNTT_EDEVICE, "event timing failed: %s", hipGetErrorString(e));
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
+}
+
+// ---- C ABI: prime64 ---------------------------------------------------------------------------
+#define CNTT_PRIME_API(BITS, T, PLAN)                                                                               \
+    extern "C" int cntt_prime##BITS##_plan_new(size_t n, T p, PLAN **out) { return plan_new<T, PLAN>(n, p, out); }  \
+    extern "C" PLAN *cntt_prime##BITS##_plan_clone(const PLAN *pl) {                                                \
+        if (!pl) return nullptr;                                                                                    \
+        return new (std::nothrow) PLAN(*pl); /* host tables copied, immutable device replicas shared */             \
+    }                                                                                                               \
+    extern "C" void cntt_prime##BITS##_plan_free(PLAN *pl) { delete pl; }                                           \
+    extern "C" size_t cntt_prime##BITS##_ntt_size(const PLAN *pl) { return pl ? pl->n : 0; }                        \
+    extern "C" T cntt_prime##BITS##_modulus(const PLAN *pl) { return pl ? pl->p : 0; }                              \
+    extern "C" int cntt_prime##BITS##_plan_info(const PLAN *pl, cntt_plan_info_t *out) { return plan_info<T>(pl, out); } \
+    extern "C" int cntt_prime##BITS##_plan_table(const PLAN *pl, cntt_table_t w, T *out, size_t len) {              \
+        return plan_table<T>(pl, w, out, len);                                                                      \
+    }                                                                                                               \
+    extern "C" int cntt_prime##BITS##_fwd(const PLAN *pl, T *buf, size_t len) {                                     \
+        if (!pl) return fail(CNTT_EINVAL, "plan is NULL");                                                          \
+        if (len != pl->n) return fail(CNTT_ELEN, "assert_eq!(buf.len(), ntt_size): %zu != %zu", len, pl->n);        \
+        return prime_op<T>(pl, 0, buf, nullptr, nullptr, len, 1, CNTT_MEM_HOST, nullptr);                           \
+    }                                                                                                               \
+    extern "C" int cntt_prime##BITS##_inv(const PLAN *pl, T *buf, size_t len) {                                     \
+        if (!pl) return fail(CNTT_EINVAL, "plan is NULL");                                                          \
+        if (len != pl->n) return fail(CNTT_ELEN, "assert_eq!(buf.len(), ntt_size): %zu != %zu", len, pl->n);        \
+        return prime_op<T>(pl, 1, buf, nullptr, nullptr, len, 1, CNTT_MEM_HOST, nullptr);                           \
+    }                                                                                                               \
+    extern "C" int cntt_prime##BITS##_mul_assign_normalize(const PLAN *pl, T *lhs, size_t ll, const T *rhs, size_t rl) { \
+        return prime_op<T>(pl, 2, lhs, rhs, nullptr, std::min(ll, rl), 0, CNTT_MEM_HOST, nullptr);                  \
+    }                                                                                                               \
+    extern "C" int cntt_prime##BITS##_normalize(const PLAN *pl, T *v, size_t len) {                                 \
+        return prime_op<T>(pl, 3, v, nullptr, nullptr, len, 0, CNTT_MEM_HOST, nullptr);                             \
+    }                                                                                                               \
+    extern "C" int cntt_prime##BITS##_mul_accumulate(const PLAN *pl, T *acc, size_t al, const T *lhs, size_t ll,    \
+                                                     const T *rhs, size_t rl) {                                     \
+        return prime_op<T>(pl, 4, acc, lhs, rhs, std::min(al, std::min(ll, rl)), 0, CNTT_MEM_HOST, nullptr);        \
+    }                                                                                                               \
+    extern "C" int cntt_prime##BITS##_fwd_batch(const PLAN *pl, T *b, size_t batch, cntt_mem_t w, void *st) {       \
+        return pl ? prime_op<T>(pl, 0, b, nullptr, nullptr, batch * pl->n, batch, w, (hipStream_t)st)               \
+                  : fail(CNTT_EINVAL, "plan is NULL");                                                              \
+    }                                                                                                               \
+    extern "C" int cntt_prime##BITS##_inv_batch(const PLAN *pl, T *b, size_t batch, cntt_mem_t w, void *st) {       \
+        return pl ? prime_op<T>(pl, 1, b, nullptr, nullptr, batch * pl->n, batch, w, (hipStream_t)st)               \
+                  : fail(CNTT_EINVAL, "plan is NULL");                                                              \
+    }                                                                                                               \
+    extern "C" int cntt_prime##BITS##_mul_assign_normalize_batch(const PLAN *pl, T *l, const T *r, size_t batch,    \
+                                                                 cntt_mem_t w, void *st) {                          \
+        return pl ? prime_op<T>(pl, 2, l, r, nullptr, batch * pl->n, batch, w, (hipStream_t)st)                     \
+                  : fail(CNTT_EINVAL, "plan is NULL");                                                              \
+    }                                                                                                               \
+    extern "C" int cntt_prime##BITS##_normalize_batch(const PLAN *pl, T *v, size_t batch, cntt_mem_t w, void *st) { \
+        return pl ? prime_op<T>(pl, 3, v, nullptr, nullptr, batch * pl->n, batch, w, (hipStream_t)st)               \
+                  : fail(CNTT_EINVAL, "plan is NULL");                                                              \
+    }                                                                                                               \
+    extern "C" int cntt_prime##BITS##_mul_accumulate_batch(const PLAN *pl, T *acc, const T *l, const T *r,          \
+                                                           size_t batch, cntt_mem_t w, void *st) {                  \
+        return pl ? prime_op<T>(pl, 4, acc, l, r, batch * pl->n, batch, w, (hipStream_t)st)                         \
+                  : fail(CNTT_EINVAL, "plan is NULL");                                                              \
+    }                                                                                                               \
+    extern "C" int cntt_prime##BITS##_time_batch(const PLAN *pl, int op, T *bufs, const T *rhs, size_t batch,       \
+                                                 int reps, void *st, float *ms) {                                   \
+        return time_batch<T>(pl, op, bufs, rhs, batch, reps, (hipStream_t)st, ms);                                  \
+    }
+
+CNTT_PRIME_API(64, uint64_t, cntt_plan64)
+CNTT_PRIME_API(32, uint32_t, cntt_plan32)
+
+// ---------------------------------------------------------------------------------------------
+// fill
+// ---------------------------------------------------------------------------------------------
+extern "C" int cntt_fill_uniform_u64(uint64_t *dst, size_t count, uint64_t bound, uint64_t seed, void *st) {
+    if (!dst && count) return fail(CNTT_EINVAL, "dst is NULL");
+    if (!count) return CNTT_OK;
+    hipLaunchKernelGGL((fill_uniform_kernel<uint64_t>), dim3(ew_grid(count)), dim3(256), 0, (hipStream_t)st, dst, count,
+                       bound, seed);
+    HIP_TRY(hipGetLastError());
+    return CNTT_OK;
+}
+extern "C" int cntt_fill_uniform_u32(uint32_t *dst, size_t count, uint32_t bound, uint64_t seed, void *st) {
+    if (!dst && count) return fail(CNTT_EINVAL, "dst is NULL");
+    if (!count) return CNTT_OK;
+    hipLaunchKernelGGL((fill_uniform_kernel<uint32_t>), dim3(ew_grid(count)), dim3(256), 0, (hipStream_t)st, dst, count,
+                       bound, seed);
+    HIP_TRY(hipGetLastError());
+    return CNTT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// native plans
+// ---------------------------------------------------------------------------------------------
+// src/lib.rs:453-462 and :601-606
+static const uint32_t PRIMES32[10] = {1062862849u, 1063059457u, 1064697857u, 1065484289u, 1068236801u,
+                                      1068433409u, 1068564481u, 1069219841u, 1071513601u, 1073479681u};
+static const uint64_t PRIMES52[6] = {1125899881086977ull, 1125899885412353ull, 1125899886395393ull,
+                                     1125899899174913ull, 1125899902124033ull, 1125899903107073ull};
+
+struct NativeKindInfo {
+    int nprimes, word, is52, binary, ngroups;
+    int ga[5], gb[5];  // prime indices of each mixed-radix group (gb = -1: single prime)
+};
+static const NativeKindInfo NATIVE_KINDS[10] = {
+    {3, 4, 0, 0, 3, {0, 1, 2, 0, 0}, {-1, -1, -1, -1, -1}},   // native32::Plan32           src/native32.rs:28-56
+    {5, 8, 0, 0, 3, {0, 1, 3, 0, 0}, {-1, 2, 4, -1, -1}},     // native64::Plan32           src/native64.rs:91-141
+    {10, 16, 0, 0, 5, {0, 2, 4, 6, 8}, {1, 3, 5, 7, 9}},      // native128::Plan32          src/native128.rs:20-118
+    {2, 4, 0, 1, 2, {0, 1, 0, 0, 0}, {-1, -1, -1, -1, -1}},   // native_binary32::Plan32    src/native_binary32.rs:22-41
+    {3, 8, 0, 1, 3, {0, 1, 2, 0, 0}, {-1, -1, -1, -1, -1}},   // native_binary64::Plan32    src/native_binary64.rs:33-61
+    {5, 16, 0, 1, 3, {0, 1, 3, 0, 0}, {-1, 2, 4, -1, -1}},    // native_binary128::Plan32   src/native_binary128.rs:13-63
+    {2, 4, 1, 0, 2, {0, 1, 0, 0, 0}, {-1, -1, -1, -1, -1}},   // native32::Plan52           src/native32.rs:223-253
+    {3, 8, 1, 0, 3, {0, 1, 2, 0, 0}, {-1, -1, -1, -1, -1}},   // native64::Plan52           src/native64.rs:770-829
+    {1, 4, 1, 1, 1, {0, 0, 0, 0, 0}, {-1, -1, -1, -1, -1}},   // native_binary32::Plan52    src/native_binary32.rs:111-125
+    {2, 8, 1, 1, 2, {0, 1, 0, 0, 0}, {-1, -1, -1, -1, -1}},   // native_binary64::Plan52    src/native_binary64.rs:230-260
+};
+
+struct Workspace {
+    void *base = nullptr;
+    size_t bytes = 0;
+};
+struct NativeCache {
+    std::mutex mu;
+    std::map<int, Workspace> ws;
+    ~NativeCache() {
+        for (auto &kv : ws) {
+            int cur = 0;
+            if (hipGetDevice(&cur) != hipSuccess) continue;
+            (void)hipSetDevice(kv.first);
+            (void)hipFree(kv.second.base);
+            (void)hipSetDevice(cur);
+        }
+    }
+};
+
+struct cntt_native {
+    cntt_native_kind_t kind;
+    NativeKindInfo info;
+    size_t n = 0;
+    std::vector<std::unique_ptr<cntt_plan32>> p32;
+    std::vector<std::unique_ptr<cntt_plan64>> p64;
+    CrtArgs crt{};
+    std::shared_ptr<NativeCache> cache;
+    size_t rbytes() const { return info.is52 ? 8 : 4; }
+    uint64_t prime(int i) const { return info.is52 ? PRIMES52[i] : (uint64_t)PRIMES32[i]; }
+};
+
+static void build_crt_args(cntt_native *pl) {
+    CrtArgs &A = pl->crt;
+    const NativeKindInfo &I = pl->info;
+    std::memset(&A, 0, sizeof A);
+    A.k = I.nprimes;
+    A.ngroups = I.ngroups;
+    for (int i = 0; i < I.nprimes; ++i) A.prime[i] = pl->prime(i);
+    u128 prefix = 1;
+    std::vector<uint64_t> M((size_t)I.ngroups);
+    for (int g = 0; g < I.ngroups; ++g) {
+        const uint64_t pa = pl->prime(I.ga[g]);
+        A.ga[g] = I.ga[g];
+        A.gb[g] = I.gb[g];
+        uint64_t m = pa;
+        if (I.gb[g] >= 0) {
+            const uint64_t pb = pl->prime(I.gb[g]);
+            A.pair_inv[g] = host::powmod(pa % pb, pb - 2, pb);  // P_a^-1 mod P_b (src/lib.rs:536-561)
+            m = pa * pb;
+        }
+        M[(size_t)g] = m;
+        A.M[g] = m;
+        A.prefix_lo[g] = (uint64_t)prefix;
+        A.prefix_hi[g] = (uint64_t)(prefix >> 64);
+        if (g > 0) {
+            // inv[g] = (M_0 ... M_{g-1})^-1 mod M[g]; M[g] is a prime or a product of two primes:
+            // invert through Euler's theorem like src/lib.rs:541-551
+            const uint64_t phi = (I.gb[g] >= 0) ? (pl->prime(I.ga[g]) - 1) * (pl->prime(I.gb[g]) - 1) : (m - 1);
+            const uint64_t pm = (uint64_t)(prefix % m);
+            A.inv[g] = host::powmod(pm, phi - 1, m);
+            A.inv_shoup[g] = (uint64_t)((((u128)A.inv[g]) << 64) / m);
+            for (int h = 0; h < g; ++h) {
+                A.Mmod[g][h] = M[(size_t)h] % m;
+                A.Mmod_shoup[g][h] = (uint64_t)((((u128)A.Mmod[g][h]) << 64) / m);
+            }
+        }
+        prefix *= (u128)m;  // wrapping mod 2^128, as src/lib.rs:592-595
+    }
+    A.prefix_lo[I.ngroups] = (uint64_t)prefix;
+    A.prefix_hi[I.ngroups] = (uint64_t)(prefix >> 64);
+}
+
+extern "C" int cntt_native_plan_new(cntt_native_kind_t kind, size_t n, cntt_native_t **out) {
+    if (!out) return fail(CNTT_EINVAL, "out is NULL");
+    *out = nullptr;
+    if ((int)kind < 0 || (int)kind > 9) return fail(CNTT_EINVAL, "unknown native plan kind");
+    std::unique_ptr<cntt_native> pl(new (std::nothrow) cntt_native());
+    if (!pl) return fail(CNTT_ENOMEM, "out of memory");
+    pl->kind = kind;
+    pl->info = NATIVE_KINDS[kind];
+    pl->n = n;
+    for (int i = 0; i < pl->info.nprimes; ++i) {  // `?` propagation: src/native64.rs:933-942
+        if (pl->info.is52) {
+            cntt_plan64 *sub = nullptr;
+            if (int rc = plan_new<uint64_t, cntt_plan64>(n, PRIMES52[i], &sub)) return rc;
+            pl->p64.emplace_back(sub);
+        } else {
+            cntt_plan32 *sub = nullptr;
+            if (int rc = plan_new<uint32_t, cntt_plan32>(n, PRIMES32[i], &sub)) return rc;
+            pl->p32.emplace_back(sub);
+        }
+    }
+    build_crt_args(pl.get());
+    pl->cache = std::make_shared<NativeCache>();
+    *out = pl.release();
+    return CNTT_OK;
+}
+
+extern "C" cntt_native_t *cntt_native_plan_clone(const cntt_native_t *pl) {
+    if (!pl) return nullptr;
+    cntt_native_t *out = nullptr;
+    if (cntt_native_plan_new(pl->kind, pl->n, &out) != CNTT_OK) return nullptr;
+    return out;
+}
+extern "C" void cntt_native_plan_free(cntt_native_t *pl) { delete pl; }
+extern "C" size_t cntt_native_ntt_size(const cntt_native_t *pl) { return pl ? pl->n : 0; }
+extern "C" int cntt_native_nprimes(const cntt_native_t *pl) { return pl ? pl->info.nprimes : 0; }
+extern "C" int cntt_native_word_bytes(const cntt_native_t *pl) { return pl ? pl->info.word : 0; }
+extern "C" int cntt_native_residue_bytes(const cntt_native_t *pl) { return pl ? (int)pl->rbytes() : 0; }
+extern "C" const cntt_plan32_t *cntt_native_ntt32(const cntt_native_t *pl, int i) {
+    if (!pl || pl->info.is52 || i < 0 || i >= pl->info.nprimes) return nullptr;
+    return pl->p32[(size_t)i].get();
+}
+extern "C" const cntt_plan64_t *cntt_native_ntt64(const cntt_native_t *pl, int i) {
+    if (!pl || !pl->info.is52 || i < 0 || i >= pl->info.nprimes) return nullptr;
+    return pl->p64[(size_t)i].get();
+}
+
+template <class W, class R> static void launch_split(const void *value, const SplitArgs &A, size_t count, bool binary, hipStream_t st) {
+    if (binary)
+        hipLaunchKernelGGL((split_kernel<W, R, true>), dim3(ew_grid(count)), dim3(256), 0, st, (const W *)value, A, count);
+    else
+        hipLaunchKernelGGL((split_kernel<W, R, false>), dim3(ew_grid(count)), dim3(256), 0, st, (const W *)value, A, count);
+}
+struct W128 {
+    uint64_t lo, hi;
+};
+static int native_split_device(const cntt_native *pl, const void *value, void *const *res, size_t count, bool binary,
+                               hipStream_t st) {
+    SplitArgs A{};
+    A.k = pl->info.nprimes;
+    for (int i = 0; i < A.k; ++i) {
+        A.res[i] = res[i];
+        A.prime[i] = pl->prime(i);
+    }
+    // a u32 word is always below the 50-bit primes: src/native32.rs:447-452 copies it without `%`
+    if (pl->info.is52) {
+        if (pl->info.word == 4)
+            launch_split<uint32_t, uint64_t>(value, A, count, true, st);
+        else
+            launch_split<uint64_t, uint64_t>(value, A, count, binary, st);
+    } else {
+        if (pl->info.word == 4)
+            launch_split<uint32_t, uint32_t>(value, A, count, binary, st);
+        else if (pl->info.word == 8)
+            launch_split<uint64_t, uint32_t>(value, A, count, binary, st);
+        else
+            launch_split<W128, uint32_t>(value, A, count, binary, st);
+    }
+    HIP_TRY(hipGetLastError());
+    return CNTT_OK;
+}
+static int native_crt_device(const cntt_native *pl, void *value, void *const *res, size_t count, hipStream_t st) {
+    CrtArgs A = pl->crt;
+    for (int i = 0; i < A.k; ++i) A.res[i] = res[i];
+    const dim3 g(ew_grid(count)), b(256);
+    if (pl->info.is52) {
+        if (pl->info.word == 4)
+            hipLaunchKernelGGL((crt_kernel<uint32_t, uint64_t>), g, b, 0, st, (uint32_t *)value, A, count);
+        else
+            hipLaunchKernelGGL((crt_kernel<uint64_t, uint64_t>), g, b, 0, st, (uint64_t *)value, A, count);
+    } else {
+        if (pl->info.word == 4)
+            hipLaunchKernelGGL((crt_kernel<uint32_t, uint32_t>), g, b, 0, st, (uint32_t *)value, A, count);
+        else if (pl->info.word == 8)
+            hipLaunchKernelGGL((crt_kernel<uint64_t, uint32_t>), g, b, 0, st, (uint64_t *)value, A, count);
+        else
+            hipLaunchKernelGGL((crt_kernel<W128, uint32_t>), g, b, 0, st, (W128 *)value, A, count);
+    }
+    HIP_TRY(hipGetLastError());
+    return CNTT_OK;
+}
+static int native_ntt_device(const cntt_native *pl, void *const *res, size_t batch, bool inv, hipStream_t st) {
+    for (int i = 0; i < pl->info.nprimes; ++i) {
+        int rc = pl->info.is52 ? ntt_device<uint64_t>(pl->p64[(size_t)i].get(), (uint64_t *)res[i], batch, inv, st)
+                               : ntt_device<uint32_t>(pl->p32[(size_t)i].get(), (uint32_t *)res[i], batch, inv, st);
+        if (rc) return rc;
+    }
+    return CNTT_OK;
+}
+
+// op: 0 fwd, 1 fwd_binary, 2 inv   (device pointers)
+static int native_op_device(const cntt_native *pl, int op, void *value, void *const *res, size_t batch, hipStream_t st) {
+    const size_t count = batch * pl->n;
+    if (op == 2) {
+        if (int rc = native_ntt_device(pl, res, batch, true, st)) return rc;
+        return native_crt_device(pl, value, res, count, st);
+    }
+    if (int rc = native_split_device(pl, value, res, count, op == 1, st)) return rc;
+    return native_ntt_device(pl, res, batch, false, st);
+}
+
+static int native_op(const cntt_native *pl, int op, void *value, void *const *res, size_t batch, cntt_mem_t where,
+                     hipStream_t st) {
+    if (!pl || !value || !res) return fail(CNTT_EINVAL, "NULL argument");
+    if (op == 1 && !pl->info.binary) return fail(CNTT_EINVAL, "fwd_binary exists only on native_binary* plans");
+    if (batch == 0) return CNTT_OK;
+    const int k = pl->info.nprimes;
+    for (int i = 0; i < k; ++i)
+        if (!res[i]) return fail(CNTT_EINVAL, "NULL residue buffer");
+    if (where == CNTT_MEM_DEVICE) return native_op_device(pl, op, value, res, batch, st);
+    const size_t count = batch * pl->n, vbytes = count * (size_t)pl->info.word, rb = count * pl->rbytes();
+    DevBuf dv;
+    std::vector<DevBuf> dr((size_t)k);
+    void *dres[10];
+    if (int rc = dv.alloc(vbytes)) return rc;
+    for (int i = 0; i < k; ++i) {
+        if (int rc = dr[(size_t)i].alloc(rb)) return rc;
+        dres[i] = dr[(size_t)i].p;
+    }
+    if (op == 2) {
+        for (int i = 0; i < k; ++i) HIP_TRY(hipMemcpyAsync(dres[i], res[i], rb, hipMemcpyHostToDevice, st));
+    } else {
+        HIP_TRY(hipMemcpyAsync(dv.p, value, vbytes, hipMemcpyHostToDevice, st));
+    }
+    if (int rc = native_op_device(pl, op, dv.p, dres, batch, st)) return rc;
+    // fwd writes the residues; inv writes the value AND the (inverse-transformed) residues: src/native64.rs:1010-1014
+    for (int i = 0; i < k; ++i) HIP_TRY(hipMemcpyAsync(res[i], dres[i], rb, hipMemcpyDeviceToHost, st));
+    if (op == 2) HIP_TRY(hipMemcpyAsync(value, dv.p, vbytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return CNTT_OK;
+}
+
+extern "C" int cntt_native_fwd(const cntt_native_t *pl, const void *value, size_t len, void *const *res) {
+    if (!pl) return fail(CNTT_EINVAL, "plan is NULL");
+    if (len != pl->n) return fail(CNTT_ELEN, "assert_eq!(buf.len(), ntt_size): %zu != %zu", len, pl->n);
+    return native_op(pl, 0, const_cast<void *>(value), res, 1, CNTT_MEM_HOST, nullptr);
+}
+extern "C" int cntt_native_fwd_binary(const cntt_native_t *pl, const void *value, size_t len, void *const *res) {
+    if (!pl) return fail(CNTT_EINVAL, "plan is NULL");
+    if (len != pl->n) return fail(CNTT_ELEN, "assert_eq!(buf.len(), ntt_size): %zu != %zu", len, pl->n);
+    return native_op(pl, 1, const_cast<void *>(value), res, 1, CNTT_MEM_HOST, nullptr);
+}
+extern "C" int cntt_native_inv(const cntt_native_t *pl, void *value, size_t len, void *const *res) {
+    if (!pl) return fail(CNTT_EINVAL, "plan is NULL");
+    if (len != pl->n) return fail(CNTT_ELEN, "assert_eq!(buf.len(), ntt_size): %zu != %zu", len, pl->n);
+    return native_op(pl, 2, value, res, 1, CNTT_MEM_HOST, nullptr);
+}
+extern "C" int cntt_native_fwd_batch(const cntt_native_t *pl, const void *value, void *const *res, size_t batch,
+                                     cntt_mem_t where, void *st) {
+    return native_op(pl, 0, const_cast<void *>(value), res, batch, where, (hipStream_t)st);
+}
+extern "C" int cntt_native_fwd_binary_batch(const cntt_native_t *pl, const void *value, void *const *res, size_t batch,
+                                            cntt_mem_t where, void *st) {
+    return native_op(pl, 1, const_cast<void *>(value), res, batch, where, (hipStream_t)st);
+}
+extern "C" int cntt_native_inv_batch(const cntt_native_t *pl, void *value, void *const *res, size_t batch,
+                                     cntt_mem_t where, void *st) {
+    return native_op(pl, 2, value, res, batch, where, (hipStream_t)st);
+}
+
+static int native_workspace(const cntt_native *pl, size_t batch, void **base) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    const size_t need = 2 * (size_t)pl->info.nprimes * batch * pl->n * pl->rbytes();
+    std::lock_guard<std::mutex> lk(pl->cache->mu);
+    Workspace &w = pl->cache->ws[dev];
+    if (w.bytes < need) {
+        if (w.base) {
+            HIP_TRY(hipDeviceSynchronize());  // the old workspace may still be in use by enqueued work
+            (void)hipFree(w.base);
+            w.base = nullptr;
+            w.bytes = 0;
+        }
+        if (hipMalloc(&w.base, need) != hipSuccess) {
+            w.base = nullptr;
+            return fail(CNTT_ENOMEM, "hipMalloc(%zu) for the native workspace failed", need);
+        }
+        w.bytes = need;
+    }
+    *base = w.base;
+    return CNTT_OK;
+}
+extern "C" int cntt_native_reserve(const cntt_native_t *pl, size_t batch) {
+    if (!pl) return fail(CNTT_EINVAL, "plan is NULL");
+    void *b = nullptr;
+    return native_workspace(pl, batch, &b);
+}
+
+// negacyclic_polymul on device memory: src/native64.rs:1042-1069 batched
+static int native_polymul_device(const cntt_native *pl, void *prod, const void *lhs, const void *rhs, size_t batch,
+                                 hipStream_t st) {
+    void *base = nullptr;
+    if (int rc = native_workspace(pl, batch, &base)) return rc;
+    const int k = pl->info.nprimes;
+    const size_t count = batch * pl->n, rb = count * pl->rbytes();
+    void *L[10], *R[10];
+    for (int i = 0; i < k; ++i) {
+        L[i] = (char *)base + (size_t)i * rb;
+        R[i] = (char *)base + (size_t)(k + i) * rb;
+    }
+    if (int rc = native_op_device(pl, 0, const_cast<void *>(lhs), L, batch, st)) return rc;
+    if (int rc = native_op_device(pl, pl->info.binary ? 1 : 0, const_cast<void *>(rhs), R, batch, st)) return rc;
+    for (int i = 0; i < k; ++i) {
+        int rc = pl->info.is52
+                     ? pointwise_device<uint64_t, PW_MUL_NORMALIZE>(pl->p64[(size_t)i].get(), (uint64_t *)L[i],
+                                                                    (const uint64_t *)R[i], nullptr, count, st)
+                     : pointwise_device<uint32_t, PW_MUL_NORMALIZE>(pl->p32[(size_t)i].get(), (uint32_t *)L[i],
+                                                                    (const uint32_t *)R[i], nullptr, count, st);
+        if (rc) return rc;
+    }
+    return native_op_device(pl, 2, prod, L, batch, st);
+}
+
+extern "C" int cntt_native_negacyclic_polymul_batch(const cntt_native_t *pl, void *prod, const void *lhs,
+                                                    const void *rhs, size_t batch, cntt_mem_t where, void *stream) {
+    if (!pl || !prod || !lhs || !rhs) return fail(CNTT_EINVAL, "NULL argument");
+    if (batch == 0) return CNTT_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (where == CNTT_MEM_DEVICE) return native_polymul_device(pl, prod, lhs, rhs, batch, st);
+    const size_t vbytes = batch * pl->n * (size_t)pl->info.word;
+    DevBuf dp, dl, dr;
+    if (int rc = dp.alloc(vbytes)) return rc;
+    if (int rc = dl.alloc(vbytes)) return rc;
+    if (int rc = dr.alloc(vbytes)) return rc;
+    HIP_TRY(hipMemcpyAsync(dl.p, lhs, vbytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(dr.p, rhs, vbytes, hipMemcpyHostToDevice, st));
+    if (int rc = native_polymul_device(pl, dp.p, dl.p, dr.p, batch, st)) return rc;
+    HIP_TRY(hipMemcpyAsync(prod, dp.p, vbytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return CNTT_OK;
+}
+extern "C" int cntt_native_negacyclic_polymul(const cntt_native_t *pl, void *prod, size_t pn, const void *lhs, size_t ln,
+                                              const void *rhs, size_t rn) {
+    if (!pl) return fail(CNTT_EINVAL, "plan is NULL");
+    // assert_eq!(n, lhs.len()); assert_eq!(n, rhs.len()) then the inner fwd asserts ntt_size: src/native64.rs:1043-1045
+    if (pn != ln || pn != rn) return fail(CNTT_ELEN, "prod/lhs/rhs lengths differ");
+    if (pn != pl->n) return fail(CNTT_ELEN, "assert_eq!(buf.len(), ntt_size): %zu != %zu", pn, pl->n);
+    return cntt_native_negacyclic_polymul_batch(pl, prod, lhs, rhs, 1, CNTT_MEM_HOST, nullptr);
+}

@@ -1,0 +1,221 @@
+// Device-side modular arithmetic for the NTT / pointwise / CRT kernels (gfx950).
+//
+// Every public result of the reference is canonical (< p) -- asserted by its tests
+// (src/prime64.rs:1234-1252, src/prime32.rs:1028-1045) -- so the device is free to pick its own
+// internal ranges; what must match is the mathematics, the root of unity and the table layout.
+// Three arithmetic classes, chosen per plan at creation from the modulus:
+//   CLS_LAZY    p < 2^(B-2): Harvey lazy butterflies, values in [0,4p) (fwd) / [0,2p) (inv), as
+//               src/prime64/less_than_62bit.rs:117-154,271-310 and src/prime32/less_than_30bit.rs
+//   CLS_STRICT  p < 2^(B-1): values in [0,2p), as src/prime64/less_than_63bit.rs:117-154,214-232
+//   CLS_GENERIC any p (used for p >= 2^(B-1), incl. Solinas): canonical values, Montgomery
+//               products against twiddles stored in Montgomery form.  The reference does exact
+//               `%`-products there (src/prime64/generic_solinas.rs:42-128): same values.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cntt {
+
+enum : int { CLS_LAZY = 0, CLS_STRICT = 1, CLS_GENERIC = 2 };
+
+// One table entry: the twiddle and its Shoup companion floor(w * 2^B / p) (CLS_GENERIC: w holds
+// w * 2^B mod p and ws is unused).  Interleaved so that one 16-byte (u64) / 8-byte (u32) load
+// fetches both.
+template <class T> struct alignas(2 * sizeof(T)) TwPair {
+    T w, ws;
+};
+
+// Per-plan scalars handed to every kernel by value (they live in SGPRs).
+template <class T> struct ModParams {
+    T p;        // modulus
+    T neg_p;    // 2^B - p
+    T two_p;    // 2p (LAZY/STRICT; wraps and is unused for GENERIC)
+    T pinv_neg; // -p^-1 mod 2^B (Montgomery, GENERIC only)
+    T n_inv, n_inv_shoup;  // N^-1 mod p and its Shoup companion (GENERIC: N^-1 * 2^B mod p, unused)
+    T p_barrett;           // floor(2^(big_q + B - 1) / p)   (src/prime64.rs:754-756)
+    T r2;                  // 2^(2B) mod p (GENERIC pointwise)
+    uint32_t big_q;        // floor(log2 p) + 1
+    uint32_t cls;
+};
+
+// ---------------------------------------------------------------------------------------------
+// wide multiplies
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t mulhi(uint32_t a, uint32_t b) { return __umulhi(a, b); }
+
+__device__ __forceinline__ uint64_t mulhi(uint64_t a, uint64_t b) {
+    // 64x64 -> high 64 from four 32x32 products; each partial sum provably fits in 64 bits, so the
+    // compiler can fold the adds into v_mad_u64_u32.
+    const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32);
+    const uint32_t b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32);
+    const uint32_t t = __umulhi(a0, b0);
+    const uint64_t m1 = (uint64_t)a1 * b0 + t;
+    const uint64_t m2 = (uint64_t)a0 * b1 + (uint32_t)m1;
+    return (uint64_t)a1 * b1 + (m1 >> 32) + (m2 >> 32);
+}
+
+// low B bits of a*b + c*d (wrapping)
+__device__ __forceinline__ uint32_t mullo2(uint32_t a, uint32_t b, uint32_t c, uint32_t d) { return a * b + c * d; }
+__device__ __forceinline__ uint64_t mullo2(uint64_t a, uint64_t b, uint64_t c, uint64_t d) {
+    const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32);
+    const uint32_t b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32);
+    const uint32_t c0 = (uint32_t)c, c1 = (uint32_t)(c >> 32);
+    const uint32_t d0 = (uint32_t)d, d1 = (uint32_t)(d >> 32);
+    uint64_t acc = (uint64_t)a0 * b0;
+    acc = (uint64_t)c0 * d0 + acc;  // wraps mod 2^64, which is what we want
+    uint32_t hi = (uint32_t)(acc >> 32);
+    hi += a0 * b1 + a1 * b0 + c0 * d1 + c1 * d0;
+    return ((uint64_t)hi << 32) | (uint32_t)acc;
+}
+
+template <class T> __device__ __forceinline__ T umin(T a, T b) { return a < b ? a : b; }
+
+// x in [0, 2m) -> [0, m)
+template <class T> __device__ __forceinline__ T csub(T x, T m) { return umin<T>(x, x - m); }
+
+// Shoup product: y * w - floor(y * ws / 2^B) * p, in [0, 2p) for any y < 2^B  (needs p < 2^(B-1))
+template <class T> __device__ __forceinline__ T shoup_mul(T y, T w, T ws, T neg_p) {
+    const T q = mulhi(y, ws);
+    return mullo2(y, w, q, neg_p);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Montgomery (GENERIC): works for every odd p < 2^B, values canonical
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t mont_mul(uint32_t a, uint32_t b, uint32_t p, uint32_t pinv_neg) {
+    const uint64_t t = (uint64_t)a * b;
+    const uint32_t m = (uint32_t)t * pinv_neg;
+    const uint64_t mp = (uint64_t)m * p;
+    // (t + mp) / 2^32, 65-bit safe: low words cancel, carry = (low(t) != 0)
+    const uint64_t u = (t >> 32) + (mp >> 32) + ((uint32_t)t != 0u);  // < 2p <= 2^33
+    return (uint32_t)(u >= p ? u - p : u);
+}
+__device__ __forceinline__ uint64_t mont_mul(uint64_t a, uint64_t b, uint64_t p, uint64_t pinv_neg) {
+    const uint64_t t_lo = a * b, t_hi = mulhi(a, b);
+    const uint64_t m = t_lo * pinv_neg;
+    const uint64_t mp_hi = mulhi(m, p);
+    const uint64_t s = t_hi + mp_hi;
+    const bool c1 = s < t_hi;
+    const uint64_t u = s + (t_lo != 0u);
+    const bool c2 = u < s;
+    return (c1 || c2 || u >= p) ? u - p : u;
+}
+template <class T> __device__ __forceinline__ T add_mod(T a, T b, T p) {  // canonical in/out, any p < 2^B
+    const T neg_b = p - b;
+    return a >= neg_b ? a - neg_b : a + b;
+}
+template <class T> __device__ __forceinline__ T sub_mod(T a, T b, T p) {
+    return a >= b ? a - b : a + (p - b);
+}
+
+// ---------------------------------------------------------------------------------------------
+// butterflies
+// ---------------------------------------------------------------------------------------------
+template <class T, int CLS> struct Bfly {
+    // forward (Cooley-Tukey): (x, y) <- (x + w y, x - w y)
+    static __device__ __forceinline__ void fwd(T &x, T &y, T w, T ws, const ModParams<T> &P) {
+        if constexpr (CLS == CLS_LAZY) {
+            x = csub<T>(x, P.two_p);
+            const T t = shoup_mul<T>(y, w, ws, P.neg_p);
+            y = x - t + P.two_p;
+            x = x + t;
+        } else if constexpr (CLS == CLS_STRICT) {
+            x = csub<T>(x, P.p);
+            const T t = csub<T>(shoup_mul<T>(y, w, ws, P.neg_p), P.p);
+            y = x - t + P.p;
+            x = x + t;
+        } else {
+            const T t = mont_mul(y, w, P.p, P.pinv_neg);
+            const T x0 = x;
+            x = add_mod<T>(x0, t, P.p);
+            y = sub_mod<T>(x0, t, P.p);
+        }
+    }
+    // inverse (Gentleman-Sande): (x, y) <- (x + y, (x - y) w)
+    static __device__ __forceinline__ void inv(T &x, T &y, T w, T ws, const ModParams<T> &P) {
+        if constexpr (CLS == CLS_LAZY) {
+            const T d = x - y + P.two_p;
+            x = csub<T>(x + y, P.two_p);
+            y = shoup_mul<T>(d, w, ws, P.neg_p);
+        } else if constexpr (CLS == CLS_STRICT) {
+            const T d = x - y + P.p;
+            x = csub<T>(x + y, P.p);
+            y = csub<T>(shoup_mul<T>(d, w, ws, P.neg_p), P.p);
+        } else {
+            const T x0 = x;
+            x = add_mod<T>(x0, y, P.p);
+            y = mont_mul(sub_mod<T>(x0, y, P.p), w, P.p, P.pinv_neg);
+        }
+    }
+    // bring a value left by the last stage into [0, p)
+    static __device__ __forceinline__ T finish_fwd(T v, const ModParams<T> &P) {
+        if constexpr (CLS == CLS_LAZY) return csub<T>(csub<T>(v, P.two_p), P.p);
+        if constexpr (CLS == CLS_STRICT) return csub<T>(v, P.p);
+        return v;
+    }
+    static __device__ __forceinline__ T finish_inv(T v, const ModParams<T> &P) {
+        if constexpr (CLS == CLS_LAZY) return csub<T>(v, P.p);
+        return v;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// pointwise kernels' arithmetic (src/prime64.rs:534-584,690-699; src/prime32.rs:383-408,...)
+// ---------------------------------------------------------------------------------------------
+template <class T> struct Wide;
+template <> struct Wide<uint32_t> {
+    static __device__ __forceinline__ void mul(uint32_t a, uint32_t b, uint32_t &lo, uint32_t &hi) {
+        const uint64_t d = (uint64_t)a * b;
+        lo = (uint32_t)d;
+        hi = (uint32_t)(d >> 32);
+    }
+};
+template <> struct Wide<uint64_t> {
+    static __device__ __forceinline__ void mul(uint64_t a, uint64_t b, uint64_t &lo, uint64_t &hi) {
+        lo = a * b;
+        hi = mulhi(a, b);
+    }
+};
+
+// a*b mod p in [0, 2p)  (Barrett as the reference: c1 = d >> (Q-1), c3 = hi(c1 * p_barrett))
+template <class T> __device__ __forceinline__ T barrett_mul_lazy(T a, T b, const ModParams<T> &P) {
+    constexpr int B = sizeof(T) * 8;
+    T lo, hi;
+    Wide<T>::mul(a, b, lo, hi);
+    const uint32_t sh = P.big_q - 1;  // 1 <= sh < B  (p >= 2 ... p < 2^(B-1))
+    const T c1 = (T)((lo >> sh) | (hi << (B - sh)));
+    const T c3 = mulhi(c1, P.p_barrett);
+    return lo - P.p * c3;
+}
+
+template <class T> __device__ __forceinline__ T mul_normalize(T a, T b, const ModParams<T> &P, bool generic) {
+    if (generic) {
+        // mont(a, b) = a b R^-1 ; mont(., n_inv R^2) = a b n_inv   (n_inv field holds n_inv * R^2 mod p)
+        const T t = mont_mul(a, b, P.p, P.pinv_neg);
+        return mont_mul(t, P.n_inv, P.p, P.pinv_neg);
+    }
+    const T prod = barrett_mul_lazy<T>(a, b, P);
+    const T t = prod * P.n_inv - mulhi(prod, P.n_inv_shoup) * P.p;
+    return csub<T>(t, P.p);
+}
+template <class T> __device__ __forceinline__ T normalize1(T a, const ModParams<T> &P, bool generic) {
+    if (generic) {
+        // n_inv field = n_inv * R^2 ; mont(a, R^-1-free) : mont(a, n_inv R^2) = a n_inv R ; one more REDC by 1
+        const T t = mont_mul(a, P.n_inv, P.p, P.pinv_neg);
+        return mont_mul(t, (T)1, P.p, P.pinv_neg);
+    }
+    const T t = a * P.n_inv - mulhi(a, P.n_inv_shoup) * P.p;
+    return csub<T>(t, P.p);
+}
+template <class T> __device__ __forceinline__ T mul_acc(T acc, T a, T b, const ModParams<T> &P, bool generic) {
+    if (generic) {
+        const T t = mont_mul(a, b, P.p, P.pinv_neg);  // a b R^-1
+        const T prod = mont_mul(t, P.r2, P.p, P.pinv_neg);
+        return add_mod<T>(acc, prod, P.p);
+    }
+    T prod = barrett_mul_lazy<T>(a, b, P);
+    prod = csub<T>(prod, P.p);
+    return csub<T>(prod + acc, P.p);
+}
+
+}  // namespace cntt

@@ -1,0 +1,26 @@
+// Launch dispatch for the LDS-resident NTT kernels: (LOGN, class, SUB) -> template instance.
+// The four instantiation units ntt_inst_{u64,u32}_{fwd,inv}.hip each define one launch_ntt<T, INV>.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ntt_arith.hpp"
+
+namespace cntt {
+
+// largest transform one workgroup keeps in LDS (gen_sched.py MAX_LDS_BYTES = 128 KiB)
+template <class T> struct MaxLdsLogN;
+template <> struct MaxLdsLogN<uint64_t> { static constexpr int value = 14; };
+template <> struct MaxLdsLogN<uint32_t> { static constexpr int value = 15; };
+template <class T> struct MinLogN;
+template <> struct MinLogN<uint64_t> { static constexpr int value = 4; };  // src/prime64.rs:709
+template <> struct MinLogN<uint32_t> { static constexpr int value = 5; };  // src/prime32.rs:635
+
+// Runs nsub independent 2^logn-point transforms stored back to back at `data`.
+// depth > 0: each transform is sub-block (sub mod 2^depth) of a 2^(logn+depth)-point polynomial
+// whose top `depth` stages are done by global_stage_kernel (logn must be MaxLdsLogN then).
+template <class T, bool INV>
+hipError_t launch_ntt(int logn, int cls, T *data, const TwPair<T> *tw, const ModParams<T> &P, uint32_t nsub,
+                      uint32_t depth, hipStream_t stream);
+
+}  // namespace cntt

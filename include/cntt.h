@@ -1,0 +1,189 @@
+/*
+ * cntt.h -- C ABI of libcntt_hip.so, the MI355X (gfx950) drop-in for the hot path of
+ * zama-ai/concrete-ntt v0.2.0: Plan::try_new / fwd / inv / mul_assign_normalize / normalize /
+ * mul_accumulate for prime32 / prime64, and the native* / native_binary* polynomial products.
+ *
+ * The reference has no FFI layer: its boundary is its public Rust API.  Each entry
+ * point below replaces the Rust item cited next to it (paths relative to the reference tree); a Rust
+ * shim re-creates the types on top (rust/ in this repo, and INTEGRATION.md).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; handles are opaque and immutable after creation
+ *     (reference plans are Send + Sync: any thread may use one plan on distinct buffers).
+ *   - status codes instead of Option / panic:
+ *       CNTT_OK       success
+ *       CNTT_NONE     try_new returned None (n too small, not a power of two, modulus not prime,
+ *                     or no primitive 2n-th root: src/prime64.rs:709-713, src/prime32.rs:635-640)
+ *       CNTT_EINVAL   the reference panics (modulus <= 1: src/fastdiv.rs:48,99) or a NULL argument
+ *       CNTT_ELEN     the reference's assert_eq!(buf.len(), ntt_size) fails (src/prime64.rs:795,873)
+ *       CNTT_EDEVICE  HIP error (no GPU, launch or copy failure) -- there is NO CPU fallback
+ *       CNTT_ENOMEM   allocation failure
+ *   - host-slice calls (no _batch suffix) mirror the Rust methods one to one: data is copied to the
+ *     current HIP device, transformed by the HIP kernels, and copied back, synchronously.
+ *   - _batch calls are the measured path: `batch` polynomials stored back to back (polynomial b at
+ *     base + b * n), in place, resident in device memory (CNTT_MEM_DEVICE) or in host memory
+ *     (CNTT_MEM_HOST: staged through the device), enqueued on `stream` (a hipStream_t, NULL = default
+ *     stream).  Device-resident calls return after enqueueing; they never synchronise.
+ */
+#ifndef CNTT_H
+#define CNTT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum cntt_status {
+    CNTT_OK = 0,
+    CNTT_NONE = 1,
+    CNTT_EINVAL = 2,
+    CNTT_ELEN = 3,
+    CNTT_EDEVICE = 4,
+    CNTT_ENOMEM = 5
+} cntt_status_t;
+
+typedef enum cntt_mem { CNTT_MEM_HOST = 0, CNTT_MEM_DEVICE = 1 } cntt_mem_t;
+
+/* which table of a prime plan (src/prime64.rs:221-236, src/prime32.rs:601-616) */
+typedef enum cntt_table {
+    CNTT_TWID = 0,
+    CNTT_TWID_SHOUP = 1,
+    CNTT_INV_TWID = 2,
+    CNTT_INV_TWID_SHOUP = 3
+} cntt_table_t;
+
+/* scalar fields of a prime plan (same struct for both widths; u32 values zero-extended) */
+typedef struct cntt_plan_info {
+    uint64_t ntt_size, modulus;
+    uint64_t p_barrett, big_q, n_inv_mod_p, n_inv_mod_p_shoup; /* src/prime64.rs:752-756 */
+    uint64_t root;      /* the primitive 2n-th root w chosen by src/roots.rs:68-91 */
+    int32_t has_shoup;  /* 0 when modulus >= 2^(B-1): no Shoup tables (src/prime64.rs:729-736) */
+    int32_t arith_class; /* device arithmetic class: 0 lazy (p < 2^(B-2)), 1 strict, 2 generic */
+} cntt_plan_info_t;
+
+const char *cntt_last_error(void);      /* thread-local description of the last non-OK status */
+int cntt_device_count(void);            /* number of visible HIP devices (0 if none / no driver) */
+const char *cntt_version(void);
+
+/* ===================================================================================== */
+/* prime64::Plan  (src/prime64.rs:221-236)                                                */
+/* ===================================================================================== */
+typedef struct cntt_plan64 cntt_plan64_t;
+
+int cntt_prime64_plan_new(size_t polynomial_size, uint64_t modulus, cntt_plan64_t **out); /* Plan::try_new  src/prime64.rs:704-771 */
+cntt_plan64_t *cntt_prime64_plan_clone(const cntt_plan64_t *plan);                        /* #[derive(Clone)] src/prime64.rs:221 */
+void cntt_prime64_plan_free(cntt_plan64_t *plan);                                         /* Drop */
+size_t cntt_prime64_ntt_size(const cntt_plan64_t *plan);                                  /* Plan::ntt_size src/prime64.rs:779-781 */
+uint64_t cntt_prime64_modulus(const cntt_plan64_t *plan);                                 /* Plan::modulus  src/prime64.rs:785-787 */
+int cntt_prime64_plan_info(const cntt_plan64_t *plan, cntt_plan_info_t *out);             /* private fields, for parity tests */
+/* copies table `which` (ntt_size words) to out; CNTT_NONE if the plan has no such table */
+int cntt_prime64_plan_table(const cntt_plan64_t *plan, cntt_table_t which, uint64_t *out, size_t len);
+
+int cntt_prime64_fwd(const cntt_plan64_t *plan, uint64_t *buf, size_t len);               /* Plan::fwd src/prime64.rs:794-865 */
+int cntt_prime64_inv(const cntt_plan64_t *plan, uint64_t *buf, size_t len);               /* Plan::inv src/prime64.rs:872-943 */
+/* Plan::mul_assign_normalize src/prime64.rs:947-1033 -- like the scalar path, processes min(lhs_len, rhs_len) */
+int cntt_prime64_mul_assign_normalize(const cntt_plan64_t *plan, uint64_t *lhs, size_t lhs_len, const uint64_t *rhs, size_t rhs_len);
+int cntt_prime64_normalize(const cntt_plan64_t *plan, uint64_t *values, size_t len);      /* Plan::normalize src/prime64.rs:1037-1082 */
+/* Plan::mul_accumulate src/prime64.rs:1085-1128 */
+int cntt_prime64_mul_accumulate(const cntt_plan64_t *plan, uint64_t *acc, size_t acc_len, const uint64_t *lhs, size_t lhs_len, const uint64_t *rhs, size_t rhs_len);
+
+int cntt_prime64_fwd_batch(const cntt_plan64_t *plan, uint64_t *bufs, size_t batch, cntt_mem_t where, void *stream);
+int cntt_prime64_inv_batch(const cntt_plan64_t *plan, uint64_t *bufs, size_t batch, cntt_mem_t where, void *stream);
+int cntt_prime64_mul_assign_normalize_batch(const cntt_plan64_t *plan, uint64_t *lhs, const uint64_t *rhs, size_t batch, cntt_mem_t where, void *stream);
+int cntt_prime64_normalize_batch(const cntt_plan64_t *plan, uint64_t *values, size_t batch, cntt_mem_t where, void *stream);
+int cntt_prime64_mul_accumulate_batch(const cntt_plan64_t *plan, uint64_t *acc, const uint64_t *lhs, const uint64_t *rhs, size_t batch, cntt_mem_t where, void *stream);
+
+/* ===================================================================================== */
+/* prime32::Plan  (src/prime32.rs:601-616)                                                */
+/* ===================================================================================== */
+typedef struct cntt_plan32 cntt_plan32_t;
+
+int cntt_prime32_plan_new(size_t polynomial_size, uint32_t modulus, cntt_plan32_t **out); /* Plan::try_new  src/prime32.rs:630-686 */
+cntt_plan32_t *cntt_prime32_plan_clone(const cntt_plan32_t *plan);
+void cntt_prime32_plan_free(cntt_plan32_t *plan);
+size_t cntt_prime32_ntt_size(const cntt_plan32_t *plan);                                  /* src/prime32.rs:694-696 */
+uint32_t cntt_prime32_modulus(const cntt_plan32_t *plan);                                 /* src/prime32.rs:700-702 */
+int cntt_prime32_plan_info(const cntt_plan32_t *plan, cntt_plan_info_t *out);
+int cntt_prime32_plan_table(const cntt_plan32_t *plan, cntt_table_t which, uint32_t *out, size_t len);
+
+int cntt_prime32_fwd(const cntt_plan32_t *plan, uint32_t *buf, size_t len);               /* Plan::fwd src/prime32.rs:709-755 */
+int cntt_prime32_inv(const cntt_plan32_t *plan, uint32_t *buf, size_t len);               /* Plan::inv src/prime32.rs:762-808 */
+int cntt_prime32_mul_assign_normalize(const cntt_plan32_t *plan, uint32_t *lhs, size_t lhs_len, const uint32_t *rhs, size_t rhs_len); /* src/prime32.rs:812-864 */
+int cntt_prime32_normalize(const cntt_plan32_t *plan, uint32_t *values, size_t len);      /* src/prime32.rs:868-899 */
+int cntt_prime32_mul_accumulate(const cntt_plan32_t *plan, uint32_t *acc, size_t acc_len, const uint32_t *lhs, size_t lhs_len, const uint32_t *rhs, size_t rhs_len); /* src/prime32.rs:902-927 */
+
+int cntt_prime32_fwd_batch(const cntt_plan32_t *plan, uint32_t *bufs, size_t batch, cntt_mem_t where, void *stream);
+int cntt_prime32_inv_batch(const cntt_plan32_t *plan, uint32_t *bufs, size_t batch, cntt_mem_t where, void *stream);
+int cntt_prime32_mul_assign_normalize_batch(const cntt_plan32_t *plan, uint32_t *lhs, const uint32_t *rhs, size_t batch, cntt_mem_t where, void *stream);
+int cntt_prime32_normalize_batch(const cntt_plan32_t *plan, uint32_t *values, size_t batch, cntt_mem_t where, void *stream);
+int cntt_prime32_mul_accumulate_batch(const cntt_plan32_t *plan, uint32_t *acc, const uint32_t *lhs, const uint32_t *rhs, size_t batch, cntt_mem_t where, void *stream);
+
+/* ===================================================================================== */
+/* native / native_binary plans                                                          */
+/*                                                                                       */
+/* One handle type; `kind` selects the reference type.  Coefficient words are u32 / u64 /  */
+/* u128 (16-byte little-endian, as Rust lays u128 out on x86-64); residues are u32 for     */
+/* Plan32 kinds and u64 for Plan52 kinds.  `residues` is an array of cntt_native_nprimes() */
+/* pointers (the reference takes them as separate mod_p0.. arguments).                     */
+/* ===================================================================================== */
+typedef enum cntt_native_kind {
+    CNTT_NATIVE32_PLAN32 = 0,         /* native32::Plan32          src/native32.rs:8-12,335-432    3 primes, u32  */
+    CNTT_NATIVE64_PLAN32 = 1,         /* native64::Plan32          src/native64.rs:16-22,930-1070  5 primes, u64  */
+    CNTT_NATIVE128_PLAN32 = 2,        /* native128::Plan32         src/native128.rs:6-17,120-349  10 primes, u128 */
+    CNTT_NATIVE_BINARY32_PLAN32 = 3,  /* native_binary32::Plan32   src/native_binary32.rs:11,187-254 2 primes, u32 */
+    CNTT_NATIVE_BINARY64_PLAN32 = 4,  /* native_binary64::Plan32   src/native_binary64.rs:17-21,342-445 3 primes, u64 */
+    CNTT_NATIVE_BINARY128_PLAN32 = 5, /* native_binary128::Plan32  src/native_binary128.rs:4-10,65-197 5 primes, u128 */
+    CNTT_NATIVE32_PLAN52 = 6,         /* native32::Plan52          src/native32.rs:19,434-496      2 x 50-bit     */
+    CNTT_NATIVE64_PLAN52 = 7,         /* native64::Plan52          src/native64.rs:29-34,1074-1165 3 x 50-bit     */
+    CNTT_NATIVE_BINARY32_PLAN52 = 8,  /* native_binary32::Plan52   src/native_binary32.rs:19,256-322 1 x 50-bit   */
+    CNTT_NATIVE_BINARY64_PLAN52 = 9   /* native_binary64::Plan52   src/native_binary64.rs:29,449-521 2 x 50-bit   */
+} cntt_native_kind_t;
+
+typedef struct cntt_native cntt_native_t;
+
+int cntt_native_plan_new(cntt_native_kind_t kind, size_t n, cntt_native_t **out);   /* PlanNN::try_new(n)  e.g. src/native64.rs:933-942 */
+cntt_native_t *cntt_native_plan_clone(const cntt_native_t *plan);
+void cntt_native_plan_free(cntt_native_t *plan);
+size_t cntt_native_ntt_size(const cntt_native_t *plan);                             /* ntt_size()  src/native64.rs:946-948 */
+int cntt_native_nprimes(const cntt_native_t *plan);
+int cntt_native_word_bytes(const cntt_native_t *plan);                              /* 4, 8 or 16 */
+int cntt_native_residue_bytes(const cntt_native_t *plan);                           /* 4 (Plan32) or 8 (Plan52) */
+/* borrowed sub-plans: ntt_0() .. ntt_k()  src/native64.rs:950-969 ; NULL if the kind does not match */
+const cntt_plan32_t *cntt_native_ntt32(const cntt_native_t *plan, int i);
+const cntt_plan64_t *cntt_native_ntt64(const cntt_native_t *plan, int i);
+
+/* fwd(value, mod_p0..)         src/native64.rs:971-999   : residues[i] <- NTT_i(value mod P_i) */
+int cntt_native_fwd(const cntt_native_t *plan, const void *value, size_t len, void *const *residues);
+/* fwd_binary(value, mod_p0..)  src/native_binary64.rs:372-389 (binary kinds only) */
+int cntt_native_fwd_binary(const cntt_native_t *plan, const void *value, size_t len, void *const *residues);
+/* inv(value, mod_p0..)         src/native64.rs:1001-1038 : residues are inverse-transformed IN PLACE, then CRT */
+int cntt_native_inv(const cntt_native_t *plan, void *value, size_t len, void *const *residues);
+/* negacyclic_polymul(prod, lhs, rhs)  src/native64.rs:1042-1069 ; CNTT_ELEN unless the three lengths are equal */
+int cntt_native_negacyclic_polymul(const cntt_native_t *plan, void *prod, size_t prod_len, const void *lhs, size_t lhs_len, const void *rhs, size_t rhs_len);
+
+int cntt_native_fwd_batch(const cntt_native_t *plan, const void *value, void *const *residues, size_t batch, cntt_mem_t where, void *stream);
+int cntt_native_fwd_binary_batch(const cntt_native_t *plan, const void *value, void *const *residues, size_t batch, cntt_mem_t where, void *stream);
+int cntt_native_inv_batch(const cntt_native_t *plan, void *value, void *const *residues, size_t batch, cntt_mem_t where, void *stream);
+/* device path uses a per-plan, per-device workspace (2 * nprimes * batch * n residues) that grows on demand;
+ * reserve it ahead of a timed or captured region with cntt_native_reserve(). */
+int cntt_native_negacyclic_polymul_batch(const cntt_native_t *plan, void *prod, const void *lhs, const void *rhs, size_t batch, cntt_mem_t where, void *stream);
+int cntt_native_reserve(const cntt_native_t *plan, size_t batch);
+
+/* ===================================================================================== */
+/* utilities (not part of the reference API)                                              */
+/* ===================================================================================== */
+/* synthetic inputs: dst[i] = mulhi64(splitmix64(seed + i), bound); bound == 0 -> raw 64 bits.
+ * u32 variant: ((splitmix64(seed + i) >> 32) * bound) >> 32.  Device memory only. */
+int cntt_fill_uniform_u64(uint64_t *dst, size_t count, uint64_t bound, uint64_t seed, void *stream);
+int cntt_fill_uniform_u32(uint32_t *dst, size_t count, uint32_t bound, uint64_t seed, void *stream);
+/* HIP-event timing on the stream the kernels run on (bench.py roofline leg): elapsed milliseconds
+ * of `reps` back-to-back launches of one batched transform. op: 0 fwd, 1 inv, 2 mul_assign_normalize */
+int cntt_prime64_time_batch(const cntt_plan64_t *plan, int op, uint64_t *bufs, const uint64_t *rhs, size_t batch, int reps, void *stream, float *ms_out);
+int cntt_prime32_time_batch(const cntt_plan32_t *plan, int op, uint32_t *bufs, const uint32_t *rhs, size_t batch, int reps, void *stream, float *ms_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CNTT_H */

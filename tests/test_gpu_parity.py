@@ -1,0 +1,440 @@
+"""GPU parity tests: the HIP path (through the C ABI of include/cntt.h) against the CPU oracle, the
+committed golden vectors, and size-independent properties at the BASELINE.json sizes.
+Everything here is bit-exact (unsigned integer arithmetic; no tolerance)."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import concrete_ntt_amd as cntt
+from concrete_ntt_amd import (native32, native64, native128, native_binary32, native_binary64, native_binary128,
+                              prime32, prime64)
+
+pytestmark = pytest.mark.gpu
+
+P62 = 4611686018427322369      # headline prime, 62-bit class (benches/ntt.rs:115)
+U64_PRIMES = [1125899904679937, 2251799813554177, P62, 9223372036853661697, 18446744069414584321,
+              18446744073707716609]                     # benches/ntt.rs:111-118: every dispatch class
+U32_PRIMES = [1062862849, 1073479681, 2147352577, 4293918721]  # README + benches/ntt.rs:87-91
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def _mod(bits):
+    return prime64 if bits == 64 else prime32
+
+
+def _torch():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch
+
+
+def to_dev(a):
+    torch = _torch()
+    sdt = np.int64 if a.dtype == np.uint64 else np.int32
+    return torch.from_numpy(a.view(sdt).copy()).cuda()
+
+
+def to_host(t, dtype):
+    return t.cpu().numpy().view(dtype)
+
+
+@pytest.fixture(scope="module")
+def plans():
+    cache = {}
+
+    def get(bits, n, p):
+        key = (bits, n, p)
+        if key not in cache:
+            cache[key] = _mod(bits).Plan.try_new(n, p)
+            assert cache[key] is not None, key
+        return cache[key]
+    return get
+
+
+@pytest.fixture(scope="module")
+def oplans(oracle):
+    cache = {}
+
+    def get(bits, n, p):
+        key = (bits, n, p)
+        if key not in cache:
+            cache[key] = oracle.Plan.try_new(n, p, bits)
+        return cache[key]
+    return get
+
+
+# ------------------------------------------------------------------------------------------------
+def test_gpu_present_and_library_loaded():
+    assert cntt.device_count() >= 1
+    assert "gfx950" in cntt.version()
+
+
+def test_readme_example(plans):
+    """BASELINE.json configs[0] / README.md:41-57 through the host-slice API (C1)."""
+    plan = plans(32, 32, 1062862849)
+    data = np.arange(32, dtype=np.uint32)
+    fwd = data.copy()
+    plan.fwd(fwd)
+    assert fwd[:8].tolist() == [8337849, 878691898, 914453352, 923715776, 1012328021, 392768238, 897146226,
+                                61013893]
+    inv = fwd.copy()
+    plan.inv(inv)
+    assert inv.tolist() == [32 * i for i in range(32)]
+
+
+def test_transforms_match_golden(golden, oracle, plans):
+    for ent in golden["transforms"]:
+        bits, n, p = ent["bits"], ent["n"], ent["p"]
+        plan = plans(bits, n, p)
+        dt = plan.dtype
+        if ent["input"] == "iota":
+            x = (np.arange(n, dtype=np.uint64) % np.uint64(p)).astype(dt)
+        else:
+            x = oracle.fill_uniform(n, p, ent["seed"], bits)
+        f = x.copy()
+        plan.fwd(f)
+        assert f[:8].tolist() == ent["fwd_head"], (bits, n, p, ent["input"])
+        assert sha(f) == ent["fwd_sha256"], (bits, n, p, ent["input"])
+        i = x.copy()
+        plan.inv(i)
+        assert i[:8].tolist() == ent["inv_head"], (bits, n, p, ent["input"])
+        assert sha(i) == ent["inv_sha256"], (bits, n, p, ent["input"])
+
+
+def _batch_case(oracle, plans, oplans, bits, n, p, batch, seed):
+    plan, ref = plans(bits, n, p), oplans(bits, n, p)
+    x = oracle.fill_uniform(batch * n, p, seed, bits)
+    for name in ("fwd", "inv"):
+        d = to_dev(x)
+        getattr(plan, name + "_batch")(d)
+        got = to_host(d, plan.dtype)
+        want = x.copy()
+        getattr(ref, name + "_batch")(want, 4)
+        bad = np.nonzero(got != want)[0]
+        assert bad.size == 0, "%s bits=%d n=%d p=%d: %d mismatches, first at %d (poly %d, index %d)" % (
+            name, bits, n, p, bad.size, bad[0], bad[0] // n, bad[0] % n)
+        assert int(got.max()) < p
+
+
+@pytest.mark.parametrize("logn", list(range(4, 17)))
+def test_u64_every_size_vs_oracle(oracle, plans, oplans, logn):
+    """All N from the try_new minimum (16) through the LDS-resident sizes (<= 16384) and the
+    global-stage path beyond; batch is ragged with respect to the polynomials-per-workgroup."""
+    n = 1 << logn
+    batch = 37 if n <= 4096 else 5
+    _batch_case(oracle, plans, oplans, 64, n, P62, batch, 1000 + logn)
+
+
+@pytest.mark.parametrize("logn", list(range(5, 17)))
+def test_u32_every_size_vs_oracle(oracle, plans, oplans, logn):
+    n = 1 << logn
+    batch = 37 if n <= 4096 else 5
+    _batch_case(oracle, plans, oplans, 32, n, 1062862849, batch, 2000 + logn)
+
+
+@pytest.mark.parametrize("p", U64_PRIMES)
+@pytest.mark.parametrize("n", [16, 256, 1024, 4096])
+def test_u64_every_class_vs_oracle(oracle, plans, oplans, p, n):
+    _batch_case(oracle, plans, oplans, 64, n, p, 9, p % 1000 + n)
+
+
+@pytest.mark.parametrize("p", U32_PRIMES)
+@pytest.mark.parametrize("n", [32, 256, 2048, 8192])
+def test_u32_every_class_vs_oracle(oracle, plans, oplans, p, n):
+    _batch_case(oracle, plans, oplans, 32, n, p, 9, p % 1000 + n)
+
+
+def test_boundary_inputs(plans, oplans):
+    """All-zero, all-(p-1) and single-spike polynomials (range edges of the lazy butterflies)."""
+    for bits, n, p in [(64, 1024, P62), (64, 1024, 9223372036853661697), (64, 64, 18446744073707716609),
+                       (32, 1024, 1073479681), (32, 1024, 2147352577), (32, 64, 4293918721)]:
+        plan, ref = plans(bits, n, p), oplans(bits, n, p)
+        dt = plan.dtype
+        cases = [np.zeros(n, dtype=dt), np.full(n, p - 1, dtype=dt)]
+        spike = np.zeros(n, dtype=dt)
+        spike[n - 1] = p - 1
+        cases.append(spike)
+        for x in cases:
+            for name in ("fwd", "inv"):
+                got, want = x.copy(), x.copy()
+                getattr(plan, name)(got)
+                getattr(ref, name)(want)
+                assert np.array_equal(got, want), (bits, n, p, name)
+
+
+def test_pointwise_golden_and_oracle(golden, oracle, plans, oplans):
+    for ent in golden["pointwise"]:
+        bits, n, p, seed = ent["bits"], ent["n"], ent["p"], ent["seed"]
+        plan = plans(bits, n, p)
+        a, b, c = (oracle.fill_uniform(n, p, seed + k, bits) for k in range(3))
+        x = a.copy()
+        plan.mul_assign_normalize(x, b)
+        assert x.tolist() == ent["mul_assign_normalize"], (bits, p)
+        x = a.copy()
+        plan.normalize(x)
+        assert x.tolist() == ent["normalize"], (bits, p)
+        acc = c.copy()
+        plan.mul_accumulate(acc, a, b)
+        assert acc.tolist() == ent["mul_accumulate"], (bits, p)
+    # batched, device-resident, odd element counts exercise the vector tail
+    for bits, n, p in [(64, 1024, P62), (64, 16, 18446744069414584321), (32, 2048, 1062862849),
+                       (32, 32, 4293918721), (64, 256, 9223372036853661697), (32, 64, 2147352577)]:
+        plan, ref = plans(bits, n, p), oplans(bits, n, p)
+        batch = 7
+        a, b, c = (oracle.fill_uniform(batch * n, p, 77 + k, bits) for k in range(3))
+        da, db, dc = to_dev(a), to_dev(b), to_dev(c)
+        plan.mul_assign_normalize_batch(da, db)
+        want = a.copy()
+        ref.mul_assign_normalize(want, b)
+        assert np.array_equal(to_host(da, plan.dtype), want)
+        da = to_dev(a)
+        plan.normalize_batch(da)
+        want = a.copy()
+        ref.normalize(want)
+        assert np.array_equal(to_host(da, plan.dtype), want)
+        plan.mul_accumulate_batch(dc, to_dev(a), db)
+        want = c.copy()
+        ref.mul_accumulate(want, a, b)
+        assert np.array_equal(to_host(dc, plan.dtype), want)
+
+
+def test_test_product_property(oracle, plans):
+    """The reference's own test_product (src/prime64.rs:1211-1267, src/prime32.rs:1006-1060):
+    inv(fwd(a) (.) fwd(b)) == N * (a (*) b) and inv(mul_assign_normalize(fwd a, fwd b)) == a (*) b."""
+    for bits, primes, sizes in ((64, U64_PRIMES, [16, 32, 64, 128, 256, 512, 1024]),
+                                (32, U32_PRIMES, [32, 64, 128, 256, 512, 1024])):
+        for p in primes:
+            for n in sizes:
+                plan = plans(bits, n, p)
+                lhs = oracle.fill_uniform(n, p, 5 * n + 1, bits)
+                rhs = oracle.fill_uniform(n, p, 5 * n + 2, bits)
+                conv = oracle.negacyclic_convolution(n, p, lhs, rhs, bits)
+                fl, fr = lhs.copy(), rhs.copy()
+                plan.fwd(fl)
+                plan.fwd(fr)
+                assert int(fl.max()) < p and int(fr.max()) < p
+                prod = fl.copy()
+                plan.mul_assign_normalize(prod, fr)
+                plan.inv(prod)
+                assert int(prod.max()) < p
+                assert np.array_equal(prod, conv), (bits, p, n)
+
+
+NATIVE = {"native32_plan32": native32.Plan32, "native64_plan32": native64.Plan32,
+          "native128_plan32": native128.Plan32, "native_binary32_plan32": native_binary32.Plan32,
+          "native_binary64_plan32": native_binary64.Plan32, "native_binary128_plan32": native_binary128.Plan32,
+          "native32_plan52": native32.Plan52, "native64_plan52": native64.Plan52,
+          "native_binary32_plan52": native_binary32.Plan52, "native_binary64_plan52": native_binary64.Plan52}
+
+
+def _native_inputs(oracle, kind, n, seed, binary):
+    ref = oracle.Native(kind, n)
+    lhs, rhs = ref.words(), ref.words()
+    raw = oracle.fill_uniform(lhs.size, 0, seed, 64)
+    raw2 = oracle.fill_uniform(rhs.size, 0, seed + 99991, 64)
+    lhs[:] = raw.astype(lhs.dtype) if lhs.dtype == np.uint64 else (raw >> np.uint64(32)).astype(np.uint32)
+    rhs[:] = raw2.astype(rhs.dtype) if rhs.dtype == np.uint64 else (raw2 >> np.uint64(32)).astype(np.uint32)
+    if binary:
+        if ref.word == 16:
+            rhs[0::2] &= np.uint64(1)
+            rhs[1::2] = 0
+        else:
+            rhs &= rhs.dtype.type(1)
+    return ref, lhs, rhs
+
+
+@pytest.mark.parametrize("kind", sorted(NATIVE))
+def test_native_polymul_golden(golden, oracle, kind):
+    L = oracle.lib()
+    for ent in [e for e in golden["polymul"] if e["kind"] == kind]:
+        n, seed, wb = ent["n"], ent["seed"], ent["wordbits"]
+        plan = NATIVE[kind].try_new(n)
+        if wb == 128:
+            lhs = np.empty(2 * n, dtype=np.uint64)
+            rhs = np.empty(2 * n, dtype=np.uint64)
+            for i in range(n):
+                lhs[2 * i + 1], lhs[2 * i] = L.orc_splitmix64(seed + 2 * i), L.orc_splitmix64(seed + 2 * i + 1)
+                rhs[2 * i + 1], rhs[2 * i] = (L.orc_splitmix64(seed + 7777 + 2 * i),
+                                              L.orc_splitmix64(seed + 7778 + 2 * i))
+            if ent["binary"]:
+                rhs[0::2] &= np.uint64(1)
+                rhs[1::2] = 0
+        else:
+            dt = np.uint64 if wb == 64 else np.uint32
+            lhs = np.array([L.orc_splitmix64(seed + i) & ((1 << wb) - 1) for i in range(n)], dtype=dt)
+            rhs = np.array([L.orc_splitmix64(seed + 7777 + i) & ((1 << wb) - 1) for i in range(n)], dtype=dt)
+            if ent["binary"]:
+                rhs &= dt(1)
+        prod = np.zeros_like(lhs)
+        plan.negacyclic_polymul(prod, lhs, rhs)
+        assert sha(prod) == ent["prod_sha256"], (kind, n)
+
+
+@pytest.mark.parametrize("kind", sorted(NATIVE))
+def test_native_vs_oracle(oracle, kind):
+    """fwd / fwd_binary / inv residues, round trip (src/native64.rs:1176-1206) and batched polymul
+    (src/native64.rs:1208-1243) against the oracle; N up to 4096 (config C3's size)."""
+    cls = NATIVE[kind]
+    for n in (32, 64, 256, 1024, 2048, 4096):
+        plan = cls.try_new(n)
+        ref, lhs, rhs = _native_inputs(oracle, kind, n, 4242 + n, cls.BINARY)
+        res_g = [np.zeros(n, dtype=plan.res_dtype) for _ in range(cls.NPRIMES)]
+        res_o = ref.residues()
+        plan.fwd(lhs, *res_g)
+        ref.fwd(lhs, res_o)
+        for a, b in zip(res_g, res_o):
+            assert np.array_equal(a, b), (kind, n, "fwd")
+        if cls.BINARY:
+            rb_g = [np.zeros(n, dtype=plan.res_dtype) for _ in range(cls.NPRIMES)]
+            rb_o = ref.residues()
+            plan.fwd_binary(rhs, *rb_g)
+            ref.fwd_binary(rhs, rb_o)
+            for a, b in zip(rb_g, rb_o):
+                assert np.array_equal(a, b), (kind, n, "fwd_binary")
+        out_g, out_o = np.zeros_like(lhs), np.zeros_like(lhs)
+        plan.inv(out_g, *res_g)
+        ref.inv(out_o, res_o)
+        assert np.array_equal(out_g, out_o), (kind, n, "inv")
+        for a, b in zip(res_g, res_o):  # inv also overwrites the residue buffers: src/native64.rs:1010-1014
+            assert np.array_equal(a, b), (kind, n, "inv residues")
+        # round trip == value * n (wrapping): src/native64.rs:1204-1206
+        if ref.word != 16:
+            assert np.array_equal(out_g, lhs * lhs.dtype.type(n))
+    # batched polymul, device resident
+    n, batch = 1024, 5
+    plan = cls.try_new(n)
+    ref = oracle.Native(kind, n)
+    wpp = n * (2 if ref.word == 16 else 1)
+    lhs = np.concatenate([_native_inputs(oracle, kind, n, 9000 + b, cls.BINARY)[1] for b in range(batch)])
+    rhs = np.concatenate([_native_inputs(oracle, kind, n, 9000 + b, cls.BINARY)[2] for b in range(batch)])
+    want = np.zeros_like(lhs)
+    ref.negacyclic_polymul_batch(want, lhs, rhs, batch, 4)
+    dl, dr = to_dev(lhs), to_dev(rhs)
+    dp = to_dev(np.zeros_like(lhs))
+    plan.negacyclic_polymul_batch(dp, dl, dr)
+    got = to_host(dp, lhs.dtype)
+    assert np.array_equal(got, want), kind
+    assert wpp * batch == lhs.size
+
+
+def test_native_crt_golden(golden, oracle):
+    """CRT kernel on arbitrary residues: feed constant-term polynomials so that inv() lands each
+    golden residue vector at index 0 (truth: mixed-radix digits with the top-digit sign rule)."""
+    for grp in golden["crt"]:
+        kind = grp["kind"]
+        cls = NATIVE[kind]
+        n = 32
+        plan = cls.try_new(n)
+        for v in grp["vectors"]:
+            res = []
+            for k, r in enumerate(v["residues"]):
+                sub = plan.ntt(k)
+                p, ninv = sub.modulus(), sub.info().n_inv_mod_p
+                buf = np.zeros(n, dtype=plan.res_dtype)
+                buf[0] = (r * ninv) % p  # fwd of a constant c is c everywhere; inv of that is n*c at index 0
+                sub.fwd(buf)
+                res.append(buf)
+            out = np.zeros(n * (2 if cls.WORD == 16 else 1), dtype=plan.word_dtype)
+            plan.inv(out, *res)
+            got = int(out[0]) | (int(out[1]) << 64) if cls.WORD == 16 else int(out[0])
+            assert got == v["value"], (kind, v)
+
+
+def test_length_mismatch_is_a_panic(plans):
+    plan = plans(64, 1024, P62)
+    with pytest.raises(cntt.Panic):
+        plan.fwd(np.zeros(512, dtype=np.uint64))
+    nat = native64.Plan32.try_new(64)
+    with pytest.raises(cntt.Panic):  # assert_eq!(n, lhs.len()): src/native64.rs:1043-1045
+        nat.negacyclic_polymul(np.zeros(64, dtype=np.uint64), np.zeros(32, dtype=np.uint64),
+                               np.zeros(64, dtype=np.uint64))
+
+
+def test_empty_batch_is_a_noop(plans):
+    torch = _torch()
+    plan = plans(64, 1024, P62)
+    plan.fwd_batch(torch.empty(0, dtype=torch.int64, device="cuda"))
+    plan.inv_batch(np.zeros(0, dtype=np.uint64))
+
+
+# ---- BASELINE.json full sizes: size-independent properties + sampled oracle comparison -----------
+def test_c2_full_size_properties(oracle, plans, oplans):
+    """configs[1]: prime64 N=1024 batch=65536, fwd + pointwise + inv on device-resident data."""
+    torch = _torch()
+    n, batch = 1024, 65536
+    plan, ref = plans(64, n, P62), oplans(64, n, P62)
+    a = torch.empty(batch * n, dtype=torch.int64, device="cuda")
+    b = torch.empty(batch * n, dtype=torch.int64, device="cuda")
+    cntt.fill_uniform(a, P62, 0x5EED0002, )
+    cntt.fill_uniform(b, P62, 0x5EED1002)
+    a0 = a.clone()
+    # sampled polynomials against the oracle (inputs regenerated on the CPU from the same seeds)
+    sample = [0, 1, 4097, 32768, 65535]
+    plan.fwd_batch(a)
+    fa = a.clone()
+    for s in sample:
+        want = oracle.fill_uniform(n, P62, 0x5EED0002 + s * n, 64)
+        assert np.array_equal(to_host(a0[s * n:(s + 1) * n], np.uint64), want)
+        ref.fwd(want)
+        assert np.array_equal(to_host(a[s * n:(s + 1) * n], np.uint64), want), s
+    # round trip: normalize(inv(fwd(x))) == x for the whole batch
+    plan.inv_batch(a)
+    plan.normalize_batch(a)
+    assert torch.equal(a, a0)
+    # polymul through the NTT domain equals the oracle's on the sampled polynomials
+    plan.fwd_batch(b)
+    plan.mul_assign_normalize_batch(fa, b)
+    plan.inv_batch(fa)
+    for s in sample:
+        x = oracle.fill_uniform(n, P62, 0x5EED0002 + s * n, 64)
+        y = oracle.fill_uniform(n, P62, 0x5EED1002 + s * n, 64)
+        ref.fwd(x)
+        ref.fwd(y)
+        ref.mul_assign_normalize(x, y)
+        ref.inv(x)
+        assert np.array_equal(to_host(fa[s * n:(s + 1) * n], np.uint64), x), s
+    # canonical outputs
+    assert int(fa.max()) < P62 and int(fa.min()) >= 0
+
+
+def test_c4_shard_size_properties(oracle, plans, oplans):
+    """configs[3] per-GPU slice: prime64 N=16384 (one polynomial per workgroup, 128 KiB of LDS),
+    a 2048-polynomial piece of the 131072-polynomial shard; round trip + sampled oracle comparison."""
+    torch = _torch()
+    n, batch = 16384, 2048
+    plan, ref = plans(64, n, P62), oplans(64, n, P62)
+    a = torch.empty(batch * n, dtype=torch.int64, device="cuda")
+    cntt.fill_uniform(a, P62, 0x5EED0004)
+    a0 = a.clone()
+    plan.fwd_batch(a)
+    for s in (0, 1023, 2047):
+        want = oracle.fill_uniform(n, P62, 0x5EED0004 + s * n, 64)
+        ref.fwd(want)
+        assert np.array_equal(to_host(a[s * n:(s + 1) * n], np.uint64), want), s
+    plan.inv_batch(a)
+    plan.normalize_batch(a)
+    assert torch.equal(a, a0)
+
+
+def test_c3_c5_native_full_n(oracle):
+    """configs[2] native64 N=4096 and configs[4] native_binary64 N=2048: batched device polymul on a
+    256-polynomial slice, every polynomial against the oracle (whose truth is pinned by the schoolbook
+    convolution in tests/test_oracle_golden.py)."""
+    for kind, n in (("native64_plan32", 4096), ("native_binary64_plan32", 2048)):
+        cls = NATIVE[kind]
+        batch = 256
+        plan = cls.try_new(n)
+        ref = oracle.Native(kind, n)
+        lhs = oracle.fill_uniform(batch * n, 0, 0x5EED0003, 64)
+        rhs = oracle.fill_uniform(batch * n, 0, 0x5EED1003, 64)
+        if cls.BINARY:
+            rhs &= np.uint64(1)
+        want = np.zeros_like(lhs)
+        ref.negacyclic_polymul_batch(want, lhs, rhs, batch, 8)
+        dp = to_dev(np.zeros_like(lhs))
+        plan.negacyclic_polymul_batch(dp, to_dev(lhs), to_dev(rhs))
+        assert np.array_equal(to_host(dp, np.uint64), want), kind

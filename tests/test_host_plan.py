@@ -1,0 +1,123 @@
+"""CPU-only checks of the product's host side: plan construction (its own number theory, separate
+code from the oracle) against the golden vectors and the oracle, the C-ABI surface, error mapping.
+No compute entry point is called here (they need a GPU and have no fallback)."""
+import ctypes
+import hashlib
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import concrete_ntt_amd as cntt
+from concrete_ntt_amd import _lib, prime32, prime64
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def _mod(bits):
+    return prime64 if bits == 64 else prime32
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = os.path.join(ROOT, "include", "cntt.h")
+    pre = subprocess.run(["gcc", "-E", "-P", hdr], check=True, capture_output=True, text=True).stdout
+    names = sorted(set(re.findall(r"\b(cntt_[a-z0-9_]+)\s*\(", pre)))
+    assert len(names) >= 59
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+
+
+def test_plans_match_golden(golden):
+    for ent in golden["plans"]:
+        pl = _mod(ent["bits"]).Plan.try_new(ent["n"], ent["p"])
+        assert pl is not None
+        info = pl.info()
+        assert (info.ntt_size, info.modulus, info.root) == (ent["n"], ent["p"], ent["w"])
+        assert (info.n_inv_mod_p, info.big_q, bool(info.has_shoup)) == (ent["n_inv"], ent["big_q"], ent["has_shoup"])
+        assert pl.table(_lib.TWID)[:8].tolist() == ent["twid_head"]
+        assert sha(pl.table(_lib.TWID)) == ent["twid_sha256"]
+        assert sha(pl.table(_lib.INV_TWID)) == ent["inv_twid_sha256"]
+        if ent["has_shoup"]:
+            assert (info.n_inv_mod_p_shoup, info.p_barrett) == (ent["n_inv_shoup"], ent["p_barrett"])
+            assert pl.table(_lib.TWID_SHOUP)[:8].tolist() == ent["twid_shoup_head"]
+            assert pl.table(_lib.INV_TWID_SHOUP)[:8].tolist() == ent["inv_twid_shoup_head"]
+            assert sha(pl.table(_lib.TWID_SHOUP)) == ent["twid_shoup_sha256"]
+        else:
+            assert pl.table(_lib.TWID_SHOUP) is None
+        assert pl.ntt_size() == ent["n"] and pl.modulus() == ent["p"]
+
+
+@pytest.mark.parametrize("bits,n,p", [(64, 4096, 4611686018427322369), (64, 2048, 18446744069414584321),
+                                      (64, 512, 9223372036853661697), (32, 8192, 1073479681),
+                                      (32, 256, 4293918721), (32, 2048, 2147352577)])
+def test_plans_match_oracle(oracle, bits, n, p):
+    pl = _mod(bits).Plan.try_new(n, p)
+    ref = oracle.Plan.try_new(n, p, bits)
+    for which, name in ((_lib.TWID, "twid"), (_lib.TWID_SHOUP, "twid_shoup"), (_lib.INV_TWID, "inv_twid"),
+                        (_lib.INV_TWID_SHOUP, "inv_twid_shoup")):
+        a, b = pl.table(which), ref.table(name)
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert np.array_equal(a, b), name
+    info = pl.info()
+    assert (info.n_inv_mod_p, info.big_q) == (ref.n_inv_mod_p, ref.big_q)
+    if info.has_shoup:
+        assert (info.n_inv_mod_p_shoup, info.p_barrett) == (ref.n_inv_mod_p_shoup, ref.p_barrett)
+    expect_cls = 0 if p < (1 << (bits - 2)) else (1 if p < (1 << (bits - 1)) else 2)
+    assert info.arith_class == expect_cls
+
+
+def test_try_new_none_and_panics(golden):
+    for c in golden["try_new_none"]:
+        assert _mod(c["bits"]).Plan.try_new(c["n"], c["p"]) is None, c
+    for m in (prime64, prime32):
+        for p in (0, 1):
+            with pytest.raises(cntt.Panic):
+                m.Plan.try_new(64, p)
+    # test_plan_crash_github_11: src/prime64.rs:1879-1882
+    assert prime64.Plan.try_new(2048, 1024) is None
+
+
+def test_native_plans_host_side():
+    from concrete_ntt_amd import native32, native64, native128, native_binary32, native_binary64, native_binary128
+    kinds = [(native32.Plan32, 3, 4), (native64.Plan32, 5, 4), (native128.Plan32, 10, 4),
+             (native_binary32.Plan32, 2, 4), (native_binary64.Plan32, 3, 4), (native_binary128.Plan32, 5, 4),
+             (native32.Plan52, 2, 8), (native64.Plan52, 3, 8), (native_binary32.Plan52, 1, 8),
+             (native_binary64.Plan52, 2, 8)]
+    p32 = [1062862849, 1063059457, 1064697857, 1065484289, 1068236801, 1068433409, 1068564481, 1069219841,
+           1071513601, 1073479681]  # src/lib.rs:453-462
+    p52 = [1125899881086977, 1125899885412353, 1125899886395393]  # src/lib.rs:601-603
+    for cls, k, res in kinds:
+        pl = cls.try_new(256)
+        assert pl is not None and pl.ntt_size() == 256
+        assert _lib.lib().cntt_native_nprimes(pl._h) == k
+        for i in range(k):
+            sub = pl.ntt(i)
+            assert sub.ntt_size() == 256 and sub.modulus() == (p52 if res == 8 else p32)[i]
+        assert pl.ntt(k) is None
+        assert cls.try_new(16) is None or res == 8      # prime32 needs n >= 32, prime64 n >= 16
+        assert cls.try_new(1 << 17) is None             # the primes are 1 mod 2^17 only
+        assert cls.try_new(48) is None
+
+
+def test_no_gpu_means_loud_failure():
+    if cntt.device_count() > 0:
+        pytest.skip("a GPU is present")
+    pl = prime64.Plan.try_new(64, 4611686018427322369)
+    with pytest.raises(cntt.DeviceError):
+        pl.fwd(np.zeros(64, dtype=np.uint64))
+
+
+def test_length_assert_is_a_panic():
+    pl = prime32.Plan.try_new(64, 1062862849)
+    with pytest.raises(cntt.Panic):  # assert_eq!(buf.len(), self.ntt_size()): src/prime32.rs:710
+        pl.fwd(np.zeros(32, dtype=np.uint32))
+    with pytest.raises(cntt.Panic):
+        pl.inv(np.zeros(128, dtype=np.uint32))
