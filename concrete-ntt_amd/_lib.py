@@ -45,6 +45,12 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise ImportError("libcntt_hip.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "or `make -C concrete-ntt_amd/csrc` (there is no CPU fallback)")
+    try:
+        # PyTorch-ROCm bundles its own HIP runtime; load it first so that this library binds to the same
+        # runtime instance (two HIP runtimes in one process leave torch without a device).
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = ctypes.CDLL(LIB_PATH)
     L.cntt_last_error.restype = ctypes.c_char_p
     L.cntt_version.restype = ctypes.c_char_p

@@ -537,7 +537,8 @@ static void build_crt_args(cntt_native *pl) {
             // inv[g] = (M_0 ... M_{g-1})^-1 mod M[g]; M[g] is a prime or a product of two primes:
             // invert through Euler's theorem like src/lib.rs:541-551
             const uint64_t phi = (I.gb[g] >= 0) ? (pl->prime(I.ga[g]) - 1) * (pl->prime(I.gb[g]) - 1) : (m - 1);
-            const uint64_t pm = (uint64_t)(prefix % m);
+            uint64_t pm = 1;  // true product M_0 ... M_{g-1} mod m (`prefix` itself wraps mod 2^128)
+            for (int h = 0; h < g; ++h) pm = host::mulmod(pm, M[(size_t)h] % m, m);
             A.inv[g] = host::powmod(pm, phi - 1, m);
             A.inv_shoup[g] = (uint64_t)((((u128)A.inv[g]) << 64) / m);
             for (int h = 0; h < g; ++h) {

@@ -126,7 +126,9 @@ def test_u64_every_size_vs_oracle(oracle, plans, oplans, logn):
     global-stage path beyond; batch is ragged with respect to the polynomials-per-workgroup."""
     n = 1 << logn
     batch = 37 if n <= 4096 else 5
-    _batch_case(oracle, plans, oplans, 64, n, P62, batch, 1000 + logn)
+    # the headline prime is 1 mod 2^16 only (N <= 32768); beyond that use the largest 62-bit prime = 1 mod 2^18
+    p = P62 if logn <= 15 else 4611686018425815041
+    _batch_case(oracle, plans, oplans, 64, n, p, batch, 1000 + logn)
 
 
 @pytest.mark.parametrize("logn", list(range(5, 17)))
