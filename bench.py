@@ -67,6 +67,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=65536, help="polynomials per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ramp-seconds", type=float, default=2.0,
+                    help="untimed back-to-back steps before the W warm-up steps, so that the timed region "
+                         "runs at the steady-state DVFS clock instead of inside the ramp from idle")
     args = ap.parse_args()
 
     import torch
@@ -106,6 +109,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # device clock ramp (untimed): the GPU idles at ~100 MHz and the package power controller needs
+    # hundreds of milliseconds of sustained load to settle (profiles/r01_power_clock_lab.txt)
+    t_ramp = time.perf_counter()
+    while time.perf_counter() - t_ramp < args.ramp_seconds:
+        for _ in range(20):
+            step()
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     fence()
@@ -120,7 +130,7 @@ def main():
         elapsed = float(t.item())
 
     # per-kernel timing with HIP events on the launch stream (roofline leg), after the timed region
-    reps = 10
+    reps = 50
     fwd_ms = plan.time_batch(0, a, reps=reps) / reps
     inv_ms = plan.time_batch(1, a, reps=reps) / reps
     mul_ms = plan.time_batch(2, a, rhs=b, reps=reps) / reps

@@ -98,6 +98,10 @@ def make_passes(bits, logn, inv, loge, first_x=None):
 
 # hand-tuned overrides: (bits, logn, inv) -> dict(first_x=.., swz=[..], block=..)
 OVERRIDES = {
+    # found by an exhaustive search over two-term XOR swizzles (score(): every exchange of the three passes
+    # plus the I/O transpose of the persistent kernel is conflict-free except one 2-way ds_write_b128)
+    (64, 10, False): {"swz": [(3, 3, 1), (6, 7, 2)]},
+    (64, 10, True): {"swz": [(3, 3, 1), (6, 7, 2)]},
 }
 
 

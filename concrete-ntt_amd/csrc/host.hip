@@ -153,6 +153,7 @@ template <class T, class PlanT> static int plan_new(size_t n, T p, PlanT **out) 
     mp.p = p;
     mp.neg_p = (T)0 - p;
     mp.two_p = (T)(2 * p);
+    mp.neg_two_p = (T)0 - (T)(2 * p);
     mp.big_q = pl->big_q;
     mp.p_barrett = pl->p_barrett;
     const uint64_t p64 = (uint64_t)p;

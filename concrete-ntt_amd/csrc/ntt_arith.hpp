@@ -30,6 +30,7 @@ template <class T> struct ModParams {
     T p;        // modulus
     T neg_p;    // 2^B - p
     T two_p;    // 2p (LAZY/STRICT; wraps and is unused for GENERIC)
+    T neg_two_p; // 2^B - 2p
     T pinv_neg; // -p^-1 mod 2^B (Montgomery, GENERIC only)
     T n_inv, n_inv_shoup;  // N^-1 mod p and its Shoup companion (GENERIC: N^-1 * 2^B mod p, unused)
     T p_barrett;           // floor(2^(big_q + B - 1) / p)   (src/prime64.rs:754-756)
@@ -44,18 +45,47 @@ template <class T> struct ModParams {
 __device__ __forceinline__ uint32_t mulhi(uint32_t a, uint32_t b) { return __umulhi(a, b); }
 
 __device__ __forceinline__ uint64_t mulhi(uint64_t a, uint64_t b) {
-    // 64x64 -> high 64 from four 32x32 products; each partial sum provably fits in 64 bits, so the
-    // compiler can fold the adds into v_mad_u64_u32.
+    // 64x64 -> high 64 from four 32x32 products.  The two cross products are summed through a 96-bit
+    // carry chain (v_add_co / v_addc / v_addc) whose upper 64 bits feed the last v_mad_u64_u32 directly:
+    // 1 v_mul_hi_u32 + 3 v_mad_u64_u32 + 3 adds, no zero-extension moves.
     const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32);
     const uint32_t b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32);
-    const uint32_t t = __umulhi(a0, b0);
-    const uint64_t m1 = (uint64_t)a1 * b0 + t;
-    const uint64_t m2 = (uint64_t)a0 * b1 + (uint32_t)m1;
-    return (uint64_t)a1 * b1 + (m1 >> 32) + (m2 >> 32);
+    const uint64_t t = __umulhi(a0, b0);
+    const uint64_t u = (uint64_t)a1 * b0 + t;  // cannot overflow: (2^32-1)^2 + 2^32-1 < 2^64
+    const uint64_t v = (uint64_t)a0 * b1;
+    const uint64_t z = (uint64_t)(((unsigned __int128)u + v) >> 32);
+    return (uint64_t)a1 * b1 + z;              // cannot overflow: the true high word is < 2^64
 }
 
 // low B bits of a*b + c*d (wrapping)
 __device__ __forceinline__ uint32_t mullo2(uint32_t a, uint32_t b, uint32_t c, uint32_t d) { return a * b + c * d; }
+#ifndef CNTT_MULLO2_MODE
+#define CNTT_MULLO2_MODE 1
+#endif
+// acc.lo += a * b with the upper half of acc as scratch: ONE v_mad_u64_u32 instead of v_mul_lo_u32 + add.
+// (Plain C++ cannot express it: the compiler narrows a 64-bit accumulation whose upper half is dead.)
+__device__ __forceinline__ uint64_t mad_scratch_hi(uint32_t a, uint32_t b, uint64_t acc) {
+#if CNTT_MULLO2_MODE == 1
+    uint64_t r, carry;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(r), "=s"(carry) : "v"(a), "v"(b), "v"(acc));
+    return r;
+#else
+    uint64_t r = (uint64_t)a * b + acc;
+    asm("" : "+v"(r));
+    return r;
+#endif
+}
+__device__ __forceinline__ uint64_t mad_scratch_hi0(uint32_t a, uint32_t b) {
+#if CNTT_MULLO2_MODE == 1
+    uint64_t r, carry;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(r), "=s"(carry) : "v"(a), "v"(b));
+    return r;
+#else
+    uint64_t r = (uint64_t)a * b;
+    asm("" : "+v"(r));
+    return r;
+#endif
+}
 __device__ __forceinline__ uint64_t mullo2(uint64_t a, uint64_t b, uint64_t c, uint64_t d) {
     const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32);
     const uint32_t b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32);
@@ -63,15 +93,41 @@ __device__ __forceinline__ uint64_t mullo2(uint64_t a, uint64_t b, uint64_t c, u
     const uint32_t d0 = (uint32_t)d, d1 = (uint32_t)(d >> 32);
     uint64_t acc = (uint64_t)a0 * b0;
     acc = (uint64_t)c0 * d0 + acc;  // wraps mod 2^64, which is what we want
+#if CNTT_MULLO2_MODE == 0
     uint32_t hi = (uint32_t)(acc >> 32);
     hi += a0 * b1 + a1 * b0 + c0 * d1 + c1 * d0;
     return ((uint64_t)hi << 32) | (uint32_t)acc;
+#else
+    // the four cross products only matter modulo 2^32: accumulate them in the low word of a mad chain
+    uint64_t h = mad_scratch_hi0(a0, b1);
+    h = mad_scratch_hi(a1, b0, h);
+    h = mad_scratch_hi(c0, d1, h);
+    h = mad_scratch_hi(c1, d0, h);
+#if CNTT_MULLO2_MODE == 1
+    uint32_t hi;  // opaque add: otherwise the compiler folds h into the first product's addend at the price of two moves
+    asm("v_add_u32 %0, %1, %2" : "=v"(hi) : "v"((uint32_t)(acc >> 32)), "v"((uint32_t)h));
+#else
+    asm("" : "+v"(acc));
+    const uint32_t hi = (uint32_t)(acc >> 32) + (uint32_t)h;
+#endif
+    return ((uint64_t)hi << 32) | (uint32_t)acc;
+#endif
 }
 
 template <class T> __device__ __forceinline__ T umin(T a, T b) { return a < b ? a : b; }
 
 // x in [0, 2m) -> [0, m)
 template <class T> __device__ __forceinline__ T csub(T x, T m) { return umin<T>(x, x - m); }
+
+// x in [0, 4p) -> [0, 2p): select (-2p or 0) and add -- v_cmp + 2 v_cndmask + v_lshl_add_u64 for 64 bits
+template <class T> __device__ __forceinline__ T csub_two_p(T x, T two_p, T neg_two_p) {
+    if constexpr (sizeof(T) == 8) {
+        const T d = x + neg_two_p;
+        return x < two_p ? x : d;
+    } else {
+        return umin<T>(x, x - two_p);
+    }
+}
 
 // Shoup product: y * w - floor(y * ws / 2^B) * p, in [0, 2p) for any y < 2^B  (needs p < 2^(B-1))
 template <class T> __device__ __forceinline__ T shoup_mul(T y, T w, T ws, T neg_p) {
@@ -115,9 +171,9 @@ template <class T, int CLS> struct Bfly {
     // forward (Cooley-Tukey): (x, y) <- (x + w y, x - w y)
     static __device__ __forceinline__ void fwd(T &x, T &y, T w, T ws, const ModParams<T> &P) {
         if constexpr (CLS == CLS_LAZY) {
-            x = csub<T>(x, P.two_p);
+            x = csub_two_p<T>(x, P.two_p, P.neg_two_p);
             const T t = shoup_mul<T>(y, w, ws, P.neg_p);
-            y = x - t + P.two_p;
+            y = (x + P.two_p) - t;
             x = x + t;
         } else if constexpr (CLS == CLS_STRICT) {
             x = csub<T>(x, P.p);
@@ -134,8 +190,8 @@ template <class T, int CLS> struct Bfly {
     // inverse (Gentleman-Sande): (x, y) <- (x + y, (x - y) w)
     static __device__ __forceinline__ void inv(T &x, T &y, T w, T ws, const ModParams<T> &P) {
         if constexpr (CLS == CLS_LAZY) {
-            const T d = x - y + P.two_p;
-            x = csub<T>(x + y, P.two_p);
+            const T d = (x + P.two_p) - y;
+            x = csub_two_p<T>(x + y, P.two_p, P.neg_two_p);
             y = shoup_mul<T>(d, w, ws, P.neg_p);
         } else if constexpr (CLS == CLS_STRICT) {
             const T d = x - y + P.p;
@@ -149,7 +205,7 @@ template <class T, int CLS> struct Bfly {
     }
     // bring a value left by the last stage into [0, p)
     static __device__ __forceinline__ T finish_fwd(T v, const ModParams<T> &P) {
-        if constexpr (CLS == CLS_LAZY) return csub<T>(csub<T>(v, P.two_p), P.p);
+        if constexpr (CLS == CLS_LAZY) return csub<T>(csub_two_p<T>(v, P.two_p, P.neg_two_p), P.p);
         if constexpr (CLS == CLS_STRICT) return csub<T>(v, P.p);
         return v;
     }

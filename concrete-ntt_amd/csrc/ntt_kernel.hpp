@@ -70,8 +70,28 @@ template <> struct VecOf<uint32_t, 1> { using type = uint32_t; };
 template <> struct VecOf<uint32_t, 2> { using type = __attribute__((ext_vector_type(2))) uint32_t; };
 template <> struct VecOf<uint32_t, 4> { using type = __attribute__((ext_vector_type(4))) uint32_t; };
 
+// lab-only clock stamps (tools/ntt_lab.hip): per-wave shader-clock and 100 MHz real-time deltas
+__device__ unsigned long long *cntt_lab_buf;  // 2 slots per wave, set by the lab before launching
+struct LabStamp {
+    unsigned long long t0, r0;
+    __device__ __forceinline__ void begin() {
+        t0 = __builtin_amdgcn_s_memtime();
+        r0 = __builtin_amdgcn_s_memrealtime();
+    }
+    __device__ __forceinline__ void end() {
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        if ((threadIdx.x & 63) == 0) {
+            const size_t w = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+            cntt_lab_buf[2 * w] = t1 - t0;
+            cntt_lab_buf[2 * w + 1] = r1 - r0;
+        }
+    }
+};
+
 // ---- the kernel -----------------------------------------------------------------------------
-template <class T, int LOGN, bool INV, int CLS, bool SUB>
+// LAB: ablation flags for tools/ntt_lab.hip only (product instantiations use 0):
+//   1 = no per-thread twiddle loads, 2 = no LDS exchange, 4 = no global load/store, 8 = stamp clocks
+template <class T, int LOGN, bool INV, int CLS, bool SUB, int LAB = 0>
 struct NttKernel {
     static constexpr int BITS = sizeof(T) * 8;
     using S = Sched<BITS, LOGN, INV>;
@@ -92,10 +112,12 @@ struct NttKernel {
 
     static __device__ __forceinline__ void sync() {
         if constexpr (WAVE_PRIVATE) {
-            // same-wave LDS operations execute in issue order; only the compiler must not reorder
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            // Same-wave LDS operations execute in issue order, so only the COMPILER must not reorder
+            // them.  A fence builtin would also make hipcc drain vmcnt(0) here, which would serialise the
+            // prefetched global loads of the persistent kernel behind every exchange.
+            asm volatile("" ::: "memory");
             __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            asm volatile("" ::: "memory");
         } else {
             __syncthreads();
         }
@@ -142,6 +164,55 @@ struct NttKernel {
         }
     }
 
+    // ---- software-pipelined global loads (persistent kernel) ------------------------------------
+    // hipcc keeps ONE in-order vmcnt model per loop and waits for freshly issued loads at the loop header,
+    // so a prefetch written in plain C++ is waited for at once.  These loads are issued from inline asm
+    // (invisible to the compiler's counters); wait_async() is the single hand-placed counted wait.  The
+    // destination vectors must not be read between the two (they are only passed to wait_async).
+    static constexpr int ASYNC_NV = MAXV;  // elements per 16-byte load
+    using AsyncVec = __attribute__((ext_vector_type(4))) uint32_t;
+    template <uint32_t RM> static constexpr bool async_ok() { return vec_elems<RM>() == MAXV; }
+
+    template <uint32_t RM> static __device__ __forceinline__ void gather_async(AsyncVec (&v)[E / MAXV], const T *base, uint32_t ebase) {
+#pragma unroll
+        for (int j = 0; j < E; j += MAXV) {
+            const T *ptr = base + (ebase | cdep((uint32_t)j, RM));
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v[j / MAXV]) : "v"(ptr) : "memory");
+        }
+    }
+    // wait until at most YOUNGER vector-memory operations (issued after the async loads) are outstanding
+    template <int YOUNGER> static __device__ __forceinline__ void wait_async(AsyncVec (&v)[E / MAXV]) {
+        static_assert(E / MAXV == 8 || E / MAXV == 4 || E / MAXV == 16, "unexpected register tile");
+        if constexpr (E / MAXV == 8) {
+            asm volatile("s_waitcnt vmcnt(%8)"
+                         : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])
+                         : "n"(YOUNGER)
+                         : "memory");
+        } else if constexpr (E / MAXV == 4) {
+            asm volatile("s_waitcnt vmcnt(%4)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) : "n"(YOUNGER) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(%8)"
+                         : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])
+                         : "n"(YOUNGER)
+                         : "memory");
+            asm volatile("" : "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15])
+                         :
+                         : "memory");
+        }
+    }
+    static __device__ __forceinline__ void unpack_async(T (&r)[E], const AsyncVec (&v)[E / MAXV]) {
+#pragma unroll
+        for (int j = 0; j < E; j += MAXV) {
+            if constexpr (sizeof(T) == 8) {
+                r[j] = (T)v[j / MAXV][0] | ((T)v[j / MAXV][1] << 32);
+                r[j + 1] = (T)v[j / MAXV][2] | ((T)v[j / MAXV][3] << 32);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) r[j + i] = (T)v[j / MAXV][i];
+            }
+        }
+    }
+
     // position of the GI-th stage bit of mask GM in visiting order (forward: highest first)
     static constexpr int nth_stage_bit(uint32_t gm, int gi) {
         int seen = 0;
@@ -156,9 +227,62 @@ struct NttKernel {
     }
 
     // one butterfly stage (the GI-th of pass K) on the thread's registers
+    // ---- LDS twiddle image (persistent kernel): every stage whose twiddle depends on the thread gets a
+    // dense [h][u] slab, u = tid >> SHIFT enumerating the distinct values of (ebase >> (b+1)) ----
+    struct StageGeom {
+        int b, k, nhi, shift, d;
+        bool uniform;
+    };
+    static constexpr StageGeom geom(int K, int GI) {
+        const uint32_t RM = S::RMASK[K], GM = S::GMASK[K], CM = FULL & ~RM;
+        const int b = nth_stage_bit(GM, GI);
+        const int k = crank(RM, b);
+        const int shift = cpop(CM & ((2u << b) - 1u));      // thread-id bits that sit at or below bit b
+        const int dbits = cpop(CM >> (b + 1));              // thread-id bits above bit b
+        return StageGeom{b, k, 1 << (LOGE - 1 - k), shift, 1 << dbits, dbits == 0};
+    }
+    static constexpr int img_off(int K, int GI) {  // entries before stage (K, GI)
+        int off = 0;
+        for (int kk = 0; kk < NPASS; ++kk)
+            for (int gi = 0; gi < cpop(S::GMASK[kk]); ++gi) {
+                if (kk == K && gi == GI) return off;
+                const StageGeom g = geom(kk, gi);
+                if (!g.uniform) off += g.nhi * g.d;
+            }
+        return off;
+    }
+    static constexpr int IMG_ENTRIES = img_off(NPASS, 0) > 0 ? img_off(NPASS, 0) : 1;
+
     template <int K, int GI>
+    static __device__ __forceinline__ void fill_image_stage(TwPair<T> *img, const TwPair<T> *__restrict__ tw) {
+        constexpr StageGeom g = geom(K, GI);
+        if constexpr (!g.uniform) {
+            constexpr uint32_t RM = S::RMASK[K], CM = FULL & ~RM;
+            constexpr int OFF = img_off(K, GI);
+            for (uint32_t e = threadIdx.x; e < (uint32_t)(g.nhi * g.d); e += blockDim.x) {
+                const uint32_t h = e / (uint32_t)g.d, u = e % (uint32_t)g.d;
+                const uint32_t idx = (1u << (LOGN - 1 - g.b)) + (pdep<CM>(u << g.shift) >> (g.b + 1)) +
+                                     (pdep<RM>(h << (g.k + 1)) >> (g.b + 1));
+                img[OFF + e] = tw[idx];
+            }
+        }
+    }
+    template <int K = 0, int GI = 0>
+    static __device__ __forceinline__ void fill_image(TwPair<T> *img, const TwPair<T> *__restrict__ tw) {
+        if constexpr (K < NPASS) {
+            if constexpr (GI < cpop(S::GMASK[K])) {
+                fill_image_stage<K, GI>(img, tw);
+                fill_image<K, GI + 1>(img, tw);
+            } else {
+                fill_image<K + 1, 0>(img, tw);
+            }
+        }
+    }
+
+    template <int K, int GI, bool IMG = false>
     static __device__ __forceinline__ void stage(T (&r)[E], uint32_t ebase, uint32_t qpre, uint32_t depth,
-                                                 const TwPair<T> *__restrict__ tw, const ModParams<T> &P) {
+                                                 const TwPair<T> *__restrict__ tw, const ModParams<T> &P,
+                                                 uint32_t tid = 0, const TwPair<T> *img = nullptr) {
         constexpr uint32_t RM = S::RMASK[K], GM = S::GMASK[K], CM = FULL & ~RM;
         constexpr int b = nth_stage_bit(GM, GI);  // element-index bit of this stage
         constexpr int k = crank(RM, b);           // register-index bit that carries it
@@ -170,7 +294,13 @@ struct NttKernel {
         TwPair<T> w[NHI];
 #pragma unroll
         for (int h = 0; h < NHI; ++h) {
-            w[h] = tw[toff + (cdep((uint32_t)h << (k + 1), RM) >> (b + 1))];
+            constexpr StageGeom g = geom(K, GI);
+            if constexpr ((LAB & 1) != 0)
+                w[h] = tw[(1u << (LOGN - 1 - b)) + (uint32_t)h];  // uniform address: scalar load
+            else if constexpr (IMG && !g.uniform)
+                w[h] = img[img_off(K, GI) + h * g.d + (tid >> g.shift)];
+            else
+                w[h] = tw[toff + (cdep((uint32_t)h << (k + 1), RM) >> (b + 1))];
         }
 #pragma unroll
         for (int j = 0; j < E; ++j) {
@@ -183,12 +313,13 @@ struct NttKernel {
         }
     }
 
-    template <int K, int GI = 0>
+    template <int K, int GI = 0, bool IMG = false>
     static __device__ __forceinline__ void stages(T (&r)[E], uint32_t ebase, uint32_t qpre, uint32_t depth,
-                                                  const TwPair<T> *__restrict__ tw, const ModParams<T> &P) {
+                                                  const TwPair<T> *__restrict__ tw, const ModParams<T> &P,
+                                                  uint32_t tid = 0, const TwPair<T> *img = nullptr) {
         if constexpr (GI < cpop(S::GMASK[K])) {
-            stage<K, GI>(r, ebase, qpre, depth, tw, P);
-            stages<K, GI + 1>(r, ebase, qpre, depth, tw, P);
+            stage<K, GI, IMG>(r, ebase, qpre, depth, tw, P, tid, img);
+            stages<K, GI + 1, IMG>(r, ebase, qpre, depth, tw, P, tid, img);
         }
     }
 
@@ -199,19 +330,30 @@ struct NttKernel {
         constexpr uint32_t RM = S::RMASK[K], CM = FULL & ~RM;
         const uint32_t ebase = pdep<CM>(tid);
         if constexpr (K == 0) {
-            if (active) gather<RM>(r, (const T *)g, ebase, false);
-        } else {
+            if constexpr ((LAB & 4) == 0) {
+                if (active) gather<RM>(r, (const T *)g, ebase, false);
+            }
+        } else if constexpr ((LAB & 2) == 0) {
             gather<RM>(r, (const T *)lds, ebase, true);
         }
         stages<K>(r, ebase, qpre, depth, tw, P);
         if constexpr (K == NPASS - 1) {
 #pragma unroll
             for (int j = 0; j < E; ++j) r[j] = INV ? Bfly<T, CLS>::finish_inv(r[j], P) : Bfly<T, CLS>::finish_fwd(r[j], P);
-            if (active) scatter<RM>(r, g, ebase, false);
+            if constexpr ((LAB & 4) == 0) {
+                if (active) scatter<RM>(r, g, ebase, false);
+            } else {
+                T acc = 0;  // keep the work alive without the stores
+#pragma unroll
+                for (int j = 0; j < E; ++j) acc ^= r[j];
+                if (acc == (T)0x1234567) g[0] = acc;
+            }
         } else {
-            if constexpr (K > 0) sync();  // everyone has read the previous exchange before it is overwritten
-            scatter<RM>(r, lds, ebase, true);
-            sync();
+            if constexpr ((LAB & 2) == 0) {
+                if constexpr (K > 0) sync();  // everyone has read the previous exchange before it is overwritten
+                scatter<RM>(r, lds, ebase, true);
+                sync();
+            }
             run_pass<K + 1>(r, g, lds, tid, active, qpre, depth, tw, P);
         }
     }
@@ -228,15 +370,123 @@ struct NttKernel {
         if constexpr (SUB) qpre = (sub & ((1u << depth) - 1u)) << LOGN;
         T r[E];
 #pragma unroll
-        for (int j = 0; j < E; ++j) r[j] = 0;
+        for (int j = 0; j < E; ++j) r[j] = (LAB & 4) ? (T)(threadIdx.x * 77u + j) : (T)0;
+        LabStamp st;
+        if constexpr ((LAB & 8) != 0) st.begin();
         run_pass<0>(r, g, lds, tid, active, qpre, depth, tw, P);
+        if constexpr ((LAB & 8) != 0) st.end();
     }
 };
 
-template <class T, int LOGN, bool INV, int CLS, bool SUB>
-__global__ __launch_bounds__((NttKernel<T, LOGN, INV, CLS, SUB>::BLOCK)) void ntt_kernel(
+// -------------------------------------------------------------------------------------------------
+// Persistent, software-pipelined variant for polynomials that live in one wavefront (N <= 1024).
+// Each workgroup stages the thread-dependent twiddles once in LDS (fill_image) and then walks tiles of
+// WP_PPB polynomials: the global loads of tile i+1 are issued before the butterflies of tile i, and no
+// vector-memory wait sits inside the compute phase (twiddles come from LDS / scalar loads), so HBM
+// streaming overlaps the VALU-bound passes instead of alternating with them.
+// -------------------------------------------------------------------------------------------------
+template <class T, int LOGN, bool INV, int CLS, int WPB, bool STAMP = false>
+struct NttWp : NttKernel<T, LOGN, INV, CLS, false, 0> {
+    using B = NttKernel<T, LOGN, INV, CLS, false, 0>;
+    using S = typename B::S;
+    static constexpr int E = B::E, TPP = B::TPP, NPASS = B::NPASS;
+    static constexpr int BLOCK = WPB, PPB = WPB / TPP;
+    static constexpr uint32_t FULL = B::FULL;
+    static_assert(B::WAVE_PRIVATE && NPASS > 1, "wave-private multi-pass transforms only");
+
+    template <int K>
+    static __device__ __forceinline__ void pass(T (&r)[E], T *lds, uint32_t tid, const TwPair<T> *__restrict__ tw,
+                                                const TwPair<T> *img, const ModParams<T> &P) {
+        constexpr uint32_t RM = S::RMASK[K], CM = FULL & ~RM;
+        const uint32_t ebase = pdep<CM>(tid);
+        if constexpr (K > 0) B::template gather<RM>(r, (const T *)lds, ebase, true);
+        B::template stages<K, 0, true>(r, ebase, 0u, 0u, tw, P, tid, img);
+        if constexpr (K < NPASS - 1) {
+            if constexpr (K > 0) B::sync();
+            B::template scatter<RM>(r, lds, ebase, true);
+            B::sync();
+            pass<K + 1>(r, lds, tid, tw, img, P);
+        } else {
+#pragma unroll
+            for (int j = 0; j < E; ++j) r[j] = INV ? Bfly<T, CLS>::finish_inv(r[j], P) : Bfly<T, CLS>::finish_fwd(r[j], P);
+        }
+    }
+
+    // HBM is always accessed in the fully coalesced layout IO_RM (16 bytes per lane, consecutive lanes on
+    // consecutive addresses: 1 KiB per wave-instruction); when the first / last pass wants another register
+    // layout the tile takes one extra LDS transpose instead of 16-byte accesses at a 32-128 byte lane stride.
+    static constexpr int VB = (B::MAXV == 4) ? 2 : 1;
+    static constexpr uint32_t IO_RM = ((1u << VB) - 1u) | (((1u << (B::LOGE - VB)) - 1u) << (LOGN - (B::LOGE - VB)));
+
+    static __device__ __forceinline__ void run(T *__restrict__ data, const TwPair<T> *__restrict__ tw,
+                                               const ModParams<T> &P, uint32_t nsub, T *lds_all, TwPair<T> *img) {
+        LabStamp st;
+        if constexpr (STAMP) st.begin();
+        B::fill_image(img, tw);
+        __syncthreads();
+        const uint32_t tid = threadIdx.x & (TPP - 1);
+        const uint32_t pl = threadIdx.x / TPP;
+        T *lds = lds_all + ((size_t)pl << LOGN);
+        constexpr uint32_t RM0 = S::RMASK[0], CM0 = FULL & ~RM0;
+        constexpr uint32_t RML = S::RMASK[NPASS - 1], CML = FULL & ~RML;
+        constexpr uint32_t CMIO = FULL & ~IO_RM;
+        const uint32_t ebase0 = pdep<CM0>(tid), ebaseL = pdep<CML>(tid), ebaseIO = pdep<CMIO>(tid);
+        const uint32_t ntiles = (nsub + PPB - 1) / PPB;
+        T r[E];
+#pragma unroll
+        for (int j = 0; j < E; ++j) r[j] = 0;
+        uint32_t tile = blockIdx.x;
+        if (tile < ntiles) {
+            const uint32_t sub = tile * PPB + pl;
+            if (sub < nsub) B::template gather<IO_RM>(r, (const T *)(data + ((size_t)sub << LOGN)), ebaseIO, false);
+        }
+        constexpr int NST = E / B::template vec_elems<IO_RM>();  // store instructions per tile (younger than the prefetch)
+        for (; tile < ntiles; tile += gridDim.x) {
+            const uint32_t sub = tile * PPB + pl;
+            uint32_t nxt = (tile + gridDim.x) * PPB + pl;
+            const bool more = (tile + gridDim.x) < ntiles;  // wave-uniform
+            if (nxt >= nsub) nxt = nsub - 1;                // ragged tail: harmless re-read of an in-range polynomial
+            typename B::AsyncVec vn[E / B::MAXV];
+            if (more) B::template gather_async<IO_RM>(vn, (const T *)(data + ((size_t)nxt << LOGN)), ebaseIO);
+            if constexpr (RM0 != IO_RM) {  // input transpose
+                B::template scatter<IO_RM>(r, lds, ebaseIO, true);
+                B::sync();
+                B::template gather<RM0>(r, (const T *)lds, ebase0, true);
+                B::sync();
+            }
+            pass<0>(r, lds, tid, tw, img, P);
+            if constexpr (RML != IO_RM) {  // output transpose
+                B::sync();
+                B::template scatter<RML>(r, lds, ebaseL, true);
+                B::sync();
+                B::template gather<IO_RM>(r, (const T *)lds, ebaseIO, true);
+            }
+            if (sub < nsub) B::template scatter<IO_RM>(r, data + ((size_t)sub << LOGN), ebaseIO, false);
+            B::sync();  // the exchange buffer is reused by the next tile
+            if (more) {
+                // lanes of inactive polynomials skipped their stores: the counter then allows fewer
+                // outstanding operations than were issued, i.e. the wait is only stricter.
+                B::template wait_async<NST>(vn);
+                B::unpack_async(r, vn);
+            }
+        }
+        if constexpr (STAMP) st.end();
+    }
+};
+
+template <class T, int LOGN, bool INV, int CLS, int WPB, int WPW, bool STAMP = false>
+__global__ __launch_bounds__(WPB, WPW) void ntt_kernel_wp(T *__restrict__ data, const TwPair<T> *__restrict__ tw,
+                                                      const ModParams<T> P, uint32_t nsub) {
+    using K = NttWp<T, LOGN, INV, CLS, WPB, STAMP>;
+    __shared__ __attribute__((aligned(16))) T lds[(size_t)K::PPB << LOGN];
+    __shared__ __attribute__((aligned(16))) TwPair<T> img[K::B::IMG_ENTRIES];
+    K::run(data, tw, P, nsub, lds, img);
+}
+
+template <class T, int LOGN, bool INV, int CLS, bool SUB, int LAB = 0>
+__global__ __launch_bounds__((NttKernel<T, LOGN, INV, CLS, SUB, LAB>::BLOCK)) void ntt_kernel(
     T *__restrict__ data, const TwPair<T> *__restrict__ tw, const ModParams<T> P, uint32_t nsub, uint32_t depth) {
-    using K = NttKernel<T, LOGN, INV, CLS, SUB>;
+    using K = NttKernel<T, LOGN, INV, CLS, SUB, LAB>;
     __shared__ __attribute__((aligned(16))) T lds[K::LDS_ELEMS];
     K::run(data, tw, P, nsub, depth, lds);
 }

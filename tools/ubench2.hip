@@ -125,6 +125,7 @@ template <class T, int CLS, bool INV, bool VG> static void run_bfly(void *sink, 
     P.p = p;
     P.neg_p = (T)0 - p;
     P.two_p = (T)(2 * p);
+    P.neg_two_p = (T)0 - (T)(2 * p);
     P.pinv_neg = 12345;
     const int iters = 2048;
     for (int wps : {1, 2, 4}) {
