@@ -122,6 +122,15 @@ class PrimePlan:
             raise Panic("lhs and rhs must have the same shape and live in the same memory")
         check(getattr(lib(), self._p + "mul_assign_normalize_batch")(self._h, lp, rp, batch, where, stream))
 
+    def mul_ntt_batch(self, lhs, rhs_ntt):
+        """Fused lhs <- inv(mul_assign_normalize(fwd(lhs), rhs_ntt)): same values as the three calls
+        (src/prime64.rs:1254-1266), one pass over HBM for ntt_size <= 1024."""
+        lp, batch, where, stream = self._batch(lhs)
+        rp, rb, rwhere, _ = self._batch(rhs_ntt)
+        if rb != batch or rwhere != where:
+            raise Panic("lhs and rhs_ntt must have the same shape and live in the same memory")
+        check(getattr(lib(), self._p + "mul_ntt_batch")(self._h, lp, rp, batch, where, stream))
+
     def normalize_batch(self, values):
         vp, batch, where, stream = self._batch(values)
         check(getattr(lib(), self._p + "normalize_batch")(self._h, vp, batch, where, stream))
@@ -136,7 +145,7 @@ class PrimePlan:
 
     def time_batch(self, op, bufs, rhs=None, reps=1):
         """HIP-event time (ms) of `reps` back-to-back launches on the tensor's stream.
-        op: 0 fwd, 1 inv, 2 mul_assign_normalize."""
+        op: 0 fwd, 1 inv, 2 mul_assign_normalize, 5 fused mul_ntt."""
         ptr, batch, where, stream = self._batch(bufs)
         if where != _lib.MEM_DEVICE:
             raise TypeError("time_batch needs device memory")

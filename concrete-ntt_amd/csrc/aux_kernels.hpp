@@ -102,52 +102,66 @@ __global__ __launch_bounds__(256) void global_stage_kernel(T *__restrict__ data,
 // K5: residue split.  value % P_i for each prime (src/native64.rs:980-993 etc.), or plain
 // truncation for the binary operand (src/native_binary64.rs:379-385).
 // Layout: value[batch*N] words; residues[k] -> batch*N elements of R.
+// Division-free: for the 30-bit primes a word is folded 32 bits at a time with Shoup products by
+// c = 2^32 mod p (any 32-bit operand is allowed, results in [0,2p), sums stay below 4p < 2^32); the
+// 50-bit primes use one Barrett step with floor(2^64 / p).  Results are canonical, i.e. equal to `%`.
 // ---------------------------------------------------------------------------------------------
 struct SplitArgs {
     void *res[10];
     uint64_t prime[10];
-    // Lemire-style reciprocal floor(2^64 / p) + 1 for p < 2^32 operands is not needed: we use
-    // exact 64-bit `%` on the 32-bit primes via two-step reduction (see split_mod32).
+    uint32_t c[10], c_shoup[10];  // 2^32 mod p and floor(c * 2^32 / p)          (30-bit primes)
+    uint32_t one_shoup[10];       // floor(2^32 / p): Shoup companion of 1        (30-bit primes)
+    uint64_t barrett[10];         // floor(2^64 / p)                              (50-bit primes)
     int k;
 };
 
-// x mod p for a 30-bit prime p, x < 2^64: hi word first, both steps exact in 64-bit arithmetic
-__device__ __forceinline__ uint32_t mod_u64_p32(uint64_t x, uint32_t p) { return (uint32_t)(x % p); }
+// x mod p into [0, 2p) for any 32-bit x
+__device__ __forceinline__ uint32_t red32_lazy(uint32_t x, uint32_t p, uint32_t one_shoup) {
+    return x - __umulhi(x, one_shoup) * p;
+}
+// acc * 2^32 + limb  (mod p), lazily: acc < 2^32 arbitrary, result < 4p
+__device__ __forceinline__ uint32_t fold32(uint32_t acc, uint32_t limb, uint32_t p, uint32_t c, uint32_t c_shoup,
+                                           uint32_t one_shoup) {
+    const uint32_t t = acc * c - __umulhi(acc, c_shoup) * p;  // [0, 2p)
+    return t + red32_lazy(limb, p, one_shoup);                // [0, 4p)
+}
+__device__ __forceinline__ uint32_t canon4(uint32_t x, uint32_t p) {  // [0,4p) -> [0,p)
+    x = umin<uint32_t>(x, x - 2 * p);
+    return umin<uint32_t>(x, x - p);
+}
 
 template <class W, class R, bool BINARY>
 __global__ __launch_bounds__(256) void split_kernel(const W *__restrict__ value, SplitArgs A, size_t count) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
-        if constexpr (sizeof(W) == 16) {
-            // u128 as 16-byte little-endian (lo, hi)
-            const uint64_t lo = reinterpret_cast<const uint64_t *>(value)[2 * i];
-            const uint64_t hi = reinterpret_cast<const uint64_t *>(value)[2 * i + 1];
+        uint32_t limb[4] = {0, 0, 0, 0};
+        constexpr int NL = sizeof(W) / 4;
+#pragma unroll
+        for (int l = 0; l < NL; ++l) limb[l] = reinterpret_cast<const uint32_t *>(value)[i * NL + l];
+        const uint64_t lo64 = (uint64_t)limb[0] | ((uint64_t)limb[1] << 32);
 #pragma unroll 1
-            for (int k = 0; k < A.k; ++k) {
-                R r;
-                if constexpr (BINARY) {
-                    r = (R)lo;
+        for (int k = 0; k < A.k; ++k) {
+            R r;
+            if constexpr (BINARY) {
+                r = (R)lo64;  // `*value as u32` / plain copy: src/native_binary64.rs:379-385, :481-487
+            } else if constexpr (sizeof(R) == 8) {
+                // 50-bit prime, u64 word (a u32 word never reaches here: it is copied, src/native32.rs:447-452)
+                const uint64_t p = A.prime[k];
+                const uint64_t q = mulhi(lo64, A.barrett[k]);
+                uint64_t t = lo64 - q * p;  // [0, 2p)
+                r = t >= p ? t - p : t;
+            } else {
+                const uint32_t p = (uint32_t)A.prime[k];
+                uint32_t acc = limb[NL - 1];
+                if constexpr (NL == 1) {
+                    acc = red32_lazy(acc, p, A.one_shoup[k]);
                 } else {
-                    const uint64_t p = A.prime[k];
-                    // (hi * 2^64 + lo) mod p with p < 2^32: reduce hi, then fold 32 bits at a time
-                    uint64_t acc = hi % p;
-                    acc = ((acc << 32) | (lo >> 32)) % p;
-                    acc = ((acc << 32) | (lo & 0xffffffffull)) % p;
-                    r = (R)acc;
+#pragma unroll
+                    for (int l = NL - 2; l >= 0; --l) acc = fold32(acc, limb[l], p, A.c[k], A.c_shoup[k], A.one_shoup[k]);
                 }
-                reinterpret_cast<R *>(A.res[k])[i] = r;
+                r = canon4(acc, p);
             }
-        } else {
-            const W v = value[i];
-#pragma unroll 1
-            for (int k = 0; k < A.k; ++k) {
-                R r;
-                if constexpr (BINARY)
-                    r = (R)v;
-                else
-                    r = (R)((uint64_t)v % A.prime[k]);
-                reinterpret_cast<R *>(A.res[k])[i] = r;
-            }
+            reinterpret_cast<R *>(A.res[k])[i] = r;
         }
     }
 }
@@ -171,6 +185,7 @@ struct CrtArgs {
     int ga[5], gb[5];   // prime indices of each group; gb < 0: the group is the single prime ga
     uint64_t prime[10];
     uint64_t pair_inv[5];        // pair groups: P_a^-1 mod P_b
+    uint32_t pair_inv_shoup[5];  // floor(pair_inv * 2^32 / P_b)
     uint64_t M[5];               // group moduli (a prime or a product of two 30-bit primes, < 2^62)
     uint64_t inv[5];             // inv[g] = (M_0..M_{g-1})^-1 mod M[g]  (inv[0] unused)
     uint64_t inv_shoup[5];       // floor(inv[g] * 2^64 / M[g])
@@ -221,8 +236,11 @@ __global__ __launch_bounds__(256) void crt_kernel(W *__restrict__ value, CrtArgs
                     // v_b = (m_b - v_a) * P_a^-1 mod P_b ; group residue = v_a + v_b * P_a  (src/native64.rs:98-107)
                     const uint64_t pa = A.prime[A.ga[g]], pb = A.prime[A.gb[g]];
                     const uint64_t mb = reinterpret_cast<const R *>(A.res[A.gb[g]])[i];
-                    const uint64_t d = (2 * pb + mb - va) % pb;
-                    const uint64_t vb = (d * A.pair_inv[g]) % pb;  // 30-bit operands: exact in 64 bits
+                    // Shoup product by the constant P_a^-1 (any 32-bit operand), then one conditional subtraction
+                    const uint32_t pb32 = (uint32_t)pb;
+                    const uint32_t d = (uint32_t)(2 * pb + mb - va);  // < 3 * 2^30
+                    const uint32_t t = d * (uint32_t)A.pair_inv[g] - __umulhi(d, A.pair_inv_shoup[g]) * pb32;
+                    const uint64_t vb = umin<uint32_t>(t, t - pb32);
                     rg[g] = va + vb * pa;
                 } else {
                     rg[g] = va;

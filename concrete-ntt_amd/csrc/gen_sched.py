@@ -102,6 +102,12 @@ OVERRIDES = {
     # plus the I/O transpose of the persistent kernel is conflict-free except one 2-way ds_write_b128)
     (64, 10, False): {"swz": [(3, 3, 1), (6, 7, 2)]},
     (64, 10, True): {"swz": [(3, 3, 1), (6, 7, 2)]},
+    # u32 at the native64 / native_binary64 sizes: 32 coefficients per thread (same 32 data VGPRs as u64 x 16),
+    # so N=2048 lives in one wavefront and N=4096 in two, with 16-byte coalesced first/last accesses
+    (32, 11, False): {"loge": 5},
+    (32, 11, True): {"loge": 5},
+    (32, 12, False): {"loge": 5},
+    (32, 12, True): {"loge": 5},
 }
 
 

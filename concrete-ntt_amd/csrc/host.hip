@@ -285,19 +285,35 @@ struct DevBuf {
     }
 };
 
-// op: 0 fwd, 1 inv, 2 mul_assign_normalize, 3 normalize, 4 mul_accumulate ; count = total elements
+// fused lhs <- inv(mul_assign_normalize(fwd(lhs), rhs_ntt)); three launches when no fused kernel exists
+template <class T> static int mul_ntt_device(const PrimePlan<T> *pl, T *lhs, const T *rhs, size_t batch, hipStream_t st) {
+    if (batch == 0) return CNTT_OK;
+    if (batch >= ((size_t)1 << 32)) return fail(CNTT_EINVAL, "batch too large for one launch");
+    DeviceTables<T> t;
+    if (int rc = device_tables(pl, &t)) return rc;
+    const hipError_t e = launch_mul_ntt<T>(pl->logn, (int)pl->mp.cls, lhs, rhs, t.fwd, t.inv, pl->mp, (uint32_t)batch, st);
+    if (e == hipSuccess) return CNTT_OK;
+    if (e != hipErrorNotSupported) return fail(CNTT_EDEVICE, "fused product launch failed: %s", hipGetErrorString(e));
+    (void)hipGetLastError();
+    if (int rc = ntt_device<T>(pl, lhs, batch, false, st)) return rc;
+    if (int rc = pointwise_device<T, PW_MUL_NORMALIZE>(pl, lhs, rhs, nullptr, batch * pl->n, st)) return rc;
+    return ntt_device<T>(pl, lhs, batch, true, st);
+}
+
+// op: 0 fwd, 1 inv, 2 mul_assign_normalize, 3 normalize, 4 mul_accumulate, 5 mul_ntt ; count = total elements
 template <class T>
 static int prime_op(const PrimePlan<T> *pl, int op, T *a, const T *b, const T *c, size_t count, size_t batch,
                     cntt_mem_t where, hipStream_t st) {
     if (!pl) return fail(CNTT_EINVAL, "plan is NULL");
     if (count == 0) return CNTT_OK;
-    if (!a || (op == 2 && !b) || (op == 4 && (!b || !c))) return fail(CNTT_EINVAL, "NULL buffer");
+    if (!a || ((op == 2 || op == 5) && !b) || (op == 4 && (!b || !c))) return fail(CNTT_EINVAL, "NULL buffer");
     auto run = [&](T *da, const T *db, const T *dc) -> int {
         switch (op) {
         case 0: return ntt_device<T>(pl, da, batch, false, st);
         case 1: return ntt_device<T>(pl, da, batch, true, st);
         case 2: return pointwise_device<T, PW_MUL_NORMALIZE>(pl, da, db, nullptr, count, st);
         case 3: return pointwise_device<T, PW_NORMALIZE>(pl, da, nullptr, nullptr, count, st);
+        case 5: return mul_ntt_device<T>(pl, da, db, batch, st);
         default: return pointwise_device<T, PW_MUL_ACCUMULATE>(pl, da, db, dc, count, st);
         }
     };
@@ -306,7 +322,7 @@ static int prime_op(const PrimePlan<T> *pl, int op, T *a, const T *b, const T *c
     DevBuf da, db, dc;
     if (int rc = da.alloc(bytes)) return rc;
     HIP_TRY(hipMemcpyAsync(da.p, a, bytes, hipMemcpyHostToDevice, st));
-    if (op == 2 || op == 4) {
+    if (op == 2 || op == 4 || op == 5) {
         if (int rc = db.alloc(bytes)) return rc;
         HIP_TRY(hipMemcpyAsync(db.p, b, bytes, hipMemcpyHostToDevice, st));
     }
@@ -427,6 +443,11 @@ static int time_batch(const PrimePlan<T> *pl, int op, T *bufs, const T *rhs, siz
         return pl ? prime_op<T>(pl, 4, acc, l, r, batch * pl->n, batch, w, (hipStream_t)st)                         \
                   : fail(CNTT_EINVAL, "plan is NULL");                                                              \
     }                                                                                                               \
+    extern "C" int cntt_prime##BITS##_mul_ntt_batch(const PLAN *pl, T *l, const T *r, size_t batch, cntt_mem_t w,    \
+                                                    void *st) {                                                     \
+        return pl ? prime_op<T>(pl, 5, l, r, nullptr, batch * pl->n, batch, w, (hipStream_t)st)                     \
+                  : fail(CNTT_EINVAL, "plan is NULL");                                                              \
+    }                                                                                                               \
     extern "C" int cntt_prime##BITS##_time_batch(const PLAN *pl, int op, T *bufs, const T *rhs, size_t batch,       \
                                                  int reps, void *st, float *ms) {                                   \
         return time_batch<T>(pl, op, bufs, rhs, batch, reps, (hipStream_t)st, ms);                                  \
@@ -528,6 +549,7 @@ static void build_crt_args(cntt_native *pl) {
         if (I.gb[g] >= 0) {
             const uint64_t pb = pl->prime(I.gb[g]);
             A.pair_inv[g] = host::powmod(pa % pb, pb - 2, pb);  // P_a^-1 mod P_b (src/lib.rs:536-561)
+            A.pair_inv_shoup[g] = (uint32_t)((A.pair_inv[g] << 32) / pb);
             m = pa * pb;
         }
         M[(size_t)g] = m;
@@ -613,8 +635,17 @@ static int native_split_device(const cntt_native *pl, const void *value, void *c
     SplitArgs A{};
     A.k = pl->info.nprimes;
     for (int i = 0; i < A.k; ++i) {
+        const uint64_t p = pl->prime(i);
         A.res[i] = res[i];
-        A.prime[i] = pl->prime(i);
+        A.prime[i] = p;
+        if (pl->info.is52) {
+            A.barrett[i] = (uint64_t)((((u128)1) << 64) / p);
+        } else {
+            const uint64_t c = (((uint64_t)1) << 32) % p;
+            A.c[i] = (uint32_t)c;
+            A.c_shoup[i] = (uint32_t)((c << 32) / p);
+            A.one_shoup[i] = (uint32_t)((((uint64_t)1) << 32) / p);
+        }
     }
     // a u32 word is always below the 50-bit primes: src/native32.rs:447-452 copies it without `%`
     if (pl->info.is52) {
@@ -772,17 +803,18 @@ static int native_polymul_device(const cntt_native *pl, void *prod, const void *
         L[i] = (char *)base + (size_t)i * rb;
         R[i] = (char *)base + (size_t)(k + i) * rb;
     }
-    if (int rc = native_op_device(pl, 0, const_cast<void *>(lhs), L, batch, st)) return rc;
+    // rhs: split + forward transforms; lhs: split, then per prime the fused
+    // inv(mul_assign_normalize(fwd(lhs_i), rhs_i^)) (one kernel for n <= 2048, three launches otherwise); CRT.
     if (int rc = native_op_device(pl, pl->info.binary ? 1 : 0, const_cast<void *>(rhs), R, batch, st)) return rc;
+    if (int rc = native_split_device(pl, lhs, L, count, false, st)) return rc;
     for (int i = 0; i < k; ++i) {
-        int rc = pl->info.is52
-                     ? pointwise_device<uint64_t, PW_MUL_NORMALIZE>(pl->p64[(size_t)i].get(), (uint64_t *)L[i],
-                                                                    (const uint64_t *)R[i], nullptr, count, st)
-                     : pointwise_device<uint32_t, PW_MUL_NORMALIZE>(pl->p32[(size_t)i].get(), (uint32_t *)L[i],
-                                                                    (const uint32_t *)R[i], nullptr, count, st);
+        int rc = pl->info.is52 ? mul_ntt_device<uint64_t>(pl->p64[(size_t)i].get(), (uint64_t *)L[i],
+                                                         (const uint64_t *)R[i], batch, st)
+                               : mul_ntt_device<uint32_t>(pl->p32[(size_t)i].get(), (uint32_t *)L[i],
+                                                         (const uint32_t *)R[i], batch, st);
         if (rc) return rc;
     }
-    return native_op_device(pl, 2, prod, L, batch, st);
+    return native_crt_device(pl, prod, L, count, st);
 }
 
 extern "C" int cntt_native_negacyclic_polymul_batch(const cntt_native_t *pl, void *prod, const void *lhs,

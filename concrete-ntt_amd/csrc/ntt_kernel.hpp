@@ -93,6 +93,7 @@ struct LabStamp {
 //   1 = no per-thread twiddle loads, 2 = no LDS exchange, 4 = no global load/store, 8 = stamp clocks
 template <class T, int LOGN, bool INV, int CLS, bool SUB, int LAB = 0>
 struct NttKernel {
+    using elem_t = T;
     static constexpr int BITS = sizeof(T) * 8;
     using S = Sched<BITS, LOGN, INV>;
     static constexpr int LOGE = S::LOGE, E = 1 << LOGE, NPASS = S::NPASS, BLOCK = S::BLOCK;
@@ -392,7 +393,20 @@ struct NttWp : NttKernel<T, LOGN, INV, CLS, false, 0> {
     static constexpr int E = B::E, TPP = B::TPP, NPASS = B::NPASS;
     static constexpr int BLOCK = WPB, PPB = WPB / TPP;
     static constexpr uint32_t FULL = B::FULL;
-    static_assert(B::WAVE_PRIVATE && NPASS > 1, "wave-private multi-pass transforms only");
+    static_assert(NPASS > 1 && TPP <= WPB, "multi-pass transforms owned by at most one workgroup");
+
+    // exchange synchronisation.  Inside one wavefront: compiler barrier only (B::sync).  Across the waves of a
+    // workgroup: raw s_barrier behind an LDS-only wait -- __syncthreads() would also make hipcc drain vmcnt(0),
+    // i.e. wait for the prefetched global loads of the next tile at every exchange.
+    static __device__ __forceinline__ void wsync() {
+        if constexpr (B::WAVE_PRIVATE) {
+            B::sync();
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+    }
 
     template <int K>
     static __device__ __forceinline__ void pass(T (&r)[E], T *lds, uint32_t tid, const TwPair<T> *__restrict__ tw,
@@ -402,9 +416,9 @@ struct NttWp : NttKernel<T, LOGN, INV, CLS, false, 0> {
         if constexpr (K > 0) B::template gather<RM>(r, (const T *)lds, ebase, true);
         B::template stages<K, 0, true>(r, ebase, 0u, 0u, tw, P, tid, img);
         if constexpr (K < NPASS - 1) {
-            if constexpr (K > 0) B::sync();
+            if constexpr (K > 0) wsync();
             B::template scatter<RM>(r, lds, ebase, true);
-            B::sync();
+            wsync();
             pass<K + 1>(r, lds, tid, tw, img, P);
         } else {
 #pragma unroll
@@ -450,19 +464,19 @@ struct NttWp : NttKernel<T, LOGN, INV, CLS, false, 0> {
             if (more) B::template gather_async<IO_RM>(vn, (const T *)(data + ((size_t)nxt << LOGN)), ebaseIO);
             if constexpr (RM0 != IO_RM) {  // input transpose
                 B::template scatter<IO_RM>(r, lds, ebaseIO, true);
-                B::sync();
+                wsync();
                 B::template gather<RM0>(r, (const T *)lds, ebase0, true);
-                B::sync();
+                wsync();
             }
             pass<0>(r, lds, tid, tw, img, P);
             if constexpr (RML != IO_RM) {  // output transpose
-                B::sync();
+                wsync();
                 B::template scatter<RML>(r, lds, ebaseL, true);
-                B::sync();
+                wsync();
                 B::template gather<IO_RM>(r, (const T *)lds, ebaseIO, true);
             }
             if (sub < nsub) B::template scatter<IO_RM>(r, data + ((size_t)sub << LOGN), ebaseIO, false);
-            B::sync();  // the exchange buffer is reused by the next tile
+            wsync();  // the exchange buffer is reused by the next tile
             if (more) {
                 // lanes of inactive polynomials skipped their stores: the counter then allows fewer
                 // outstanding operations than were issued, i.e. the wait is only stricter.
@@ -481,6 +495,100 @@ __global__ __launch_bounds__(WPB, WPW) void ntt_kernel_wp(T *__restrict__ data, 
     __shared__ __attribute__((aligned(16))) T lds[(size_t)K::PPB << LOGN];
     __shared__ __attribute__((aligned(16))) TwPair<T> img[K::B::IMG_ENTRIES];
     K::run(data, tw, P, nsub, lds, img);
+}
+
+// -------------------------------------------------------------------------------------------------
+// Fused negacyclic product against a pre-transformed operand (the K1 -> K3 -> K2 pipeline of SURVEY 2.1):
+//     lhs <- inv( mul_assign_normalize( fwd(lhs), rhs_ntt ) )
+// i.e. what a caller of the reference writes as plan.fwd(a); plan.mul_assign_normalize(a, b_ntt); plan.inv(a)
+// (examples/mul_poly_prime.rs), in ONE pass over HBM: 3*N words of traffic instead of 7*N.  The forward
+// transform's last register layout is the inverse transform's first one (mirror schedules), so the
+// pointwise product happens in registers between the two and rhs_ntt is read in that layout.
+// -------------------------------------------------------------------------------------------------
+template <class T, int LOGN, int CLS, int WPB>
+struct MulWp {
+    using F = NttWp<T, LOGN, false, CLS, WPB>;
+    using I = NttWp<T, LOGN, true, CLS, WPB>;
+    using FB = typename F::B;
+    using IB = typename I::B;
+    static constexpr int E = FB::E, TPP = FB::TPP, NPASS = FB::NPASS, PPB = WPB / TPP;
+    static constexpr uint32_t FULL = FB::FULL;
+    static constexpr uint32_t RM0 = FB::S::RMASK[0], RMM = FB::S::RMASK[NPASS - 1], RML = IB::S::RMASK[NPASS - 1];
+    static_assert(RMM == IB::S::RMASK[0], "forward and inverse schedules must mirror each other");
+    static constexpr uint32_t IO_RM = F::IO_RM;
+
+    static __device__ __forceinline__ void run(T *__restrict__ lhs, const T *__restrict__ rhs_ntt,
+                                               const TwPair<T> *__restrict__ twf, const TwPair<T> *__restrict__ twi,
+                                               const ModParams<T> &P, uint32_t nsub, T *lds_all, TwPair<T> *imgf,
+                                               TwPair<T> *imgi) {
+        FB::fill_image(imgf, twf);
+        IB::fill_image(imgi, twi);
+        __syncthreads();
+        const uint32_t tid = threadIdx.x & (TPP - 1);
+        const uint32_t pl = threadIdx.x / TPP;
+        T *lds = lds_all + ((size_t)pl << LOGN);
+        constexpr uint32_t CM0 = FULL & ~RM0, CMM = FULL & ~RMM, CML = FULL & ~RML, CMIO = FULL & ~IO_RM;
+        const uint32_t ebase0 = pdep<CM0>(tid), ebaseM = pdep<CMM>(tid), ebaseL = pdep<CML>(tid), ebaseIO = pdep<CMIO>(tid);
+        const uint32_t ntiles = (nsub + PPB - 1) / PPB;
+        const bool generic = CLS == CLS_GENERIC;
+        T r[E];
+#pragma unroll
+        for (int j = 0; j < E; ++j) r[j] = 0;
+        uint32_t tile = blockIdx.x;
+        if (tile < ntiles) {
+            const uint32_t sub = tile * PPB + pl;
+            if (sub < nsub) FB::template gather<IO_RM>(r, (const T *)(lhs + ((size_t)sub << LOGN)), ebaseIO, false);
+        }
+        constexpr int NST = E / FB::template vec_elems<IO_RM>();
+        for (; tile < ntiles; tile += gridDim.x) {
+            const uint32_t sub = tile * PPB + pl;
+            const uint32_t subc = sub < nsub ? sub : nsub - 1;  // clamped index for the reads of a ragged tail
+            uint32_t nxt = (tile + gridDim.x) * PPB + pl;
+            const bool more = (tile + gridDim.x) < ntiles;
+            if (nxt >= nsub) nxt = nsub - 1;
+            typename FB::AsyncVec vn[E / FB::MAXV];
+            if (more) FB::template gather_async<IO_RM>(vn, (const T *)(lhs + ((size_t)nxt << LOGN)), ebaseIO);
+            if constexpr (RM0 != IO_RM) {
+                FB::template scatter<IO_RM>(r, lds, ebaseIO, true);
+                F::wsync();
+                FB::template gather<RM0>(r, (const T *)lds, ebase0, true);
+                F::wsync();
+            }
+            F::template pass<0>(r, lds, tid, twf, imgf, P);  // canonical NTT-domain values, layout RMM
+            {
+                T b[E];
+                FB::template gather<RMM>(b, rhs_ntt + ((size_t)subc << LOGN), ebaseM, false);
+#pragma unroll
+                for (int j = 0; j < E; ++j) r[j] = mul_normalize<T>(r[j], b[j], P, generic);
+            }
+            F::wsync();  // the forward transform's last exchange has been read before the inverse overwrites it
+            I::template pass<0>(r, lds, tid, twi, imgi, P);  // canonical coefficients, layout RML
+            if constexpr (RML != IO_RM) {
+                F::wsync();
+                FB::template scatter<RML>(r, lds, ebaseL, true);
+                F::wsync();
+                FB::template gather<IO_RM>(r, (const T *)lds, ebaseIO, true);
+            }
+            if (sub < nsub) FB::template scatter<IO_RM>(r, lhs + ((size_t)sub << LOGN), ebaseIO, false);
+            F::wsync();
+            if (more) {
+                FB::template wait_async<NST>(vn);
+                FB::unpack_async(r, vn);
+            }
+        }
+    }
+};
+
+template <class T, int LOGN, int CLS, int WPB, int WPW>
+__global__ __launch_bounds__(WPB, WPW) void mul_kernel_wp(T *__restrict__ lhs, const T *__restrict__ rhs_ntt,
+                                                      const TwPair<T> *__restrict__ twf,
+                                                      const TwPair<T> *__restrict__ twi, const ModParams<T> P,
+                                                      uint32_t nsub) {
+    using K = MulWp<T, LOGN, CLS, WPB>;
+    __shared__ __attribute__((aligned(16))) T lds[(size_t)K::PPB << LOGN];
+    __shared__ __attribute__((aligned(16))) TwPair<T> imgf[K::FB::IMG_ENTRIES];
+    __shared__ __attribute__((aligned(16))) TwPair<T> imgi[K::IB::IMG_ENTRIES];
+    K::run(lhs, rhs_ntt, twf, twi, P, nsub, lds, imgf, imgi);
 }
 
 template <class T, int LOGN, bool INV, int CLS, bool SUB, int LAB = 0>

@@ -23,4 +23,10 @@ template <class T, bool INV>
 hipError_t launch_ntt(int logn, int cls, T *data, const TwPair<T> *tw, const ModParams<T> &P, uint32_t nsub,
                       uint32_t depth, hipStream_t stream);
 
+// Fused lhs <- inv(mul_assign_normalize(fwd(lhs), rhs_ntt)) for transforms that live in one wavefront
+// (2^logn <= 1024).  Returns hipErrorNotSupported for other sizes (the caller then runs three launches).
+template <class T>
+hipError_t launch_mul_ntt(int logn, int cls, T *lhs, const T *rhs_ntt, const TwPair<T> *twf, const TwPair<T> *twi,
+                          const ModParams<T> &P, uint32_t nsub, hipStream_t stream);
+
 }  // namespace cntt

@@ -94,6 +94,11 @@ int cntt_prime64_inv_batch(const cntt_plan64_t *plan, uint64_t *bufs, size_t bat
 int cntt_prime64_mul_assign_normalize_batch(const cntt_plan64_t *plan, uint64_t *lhs, const uint64_t *rhs, size_t batch, cntt_mem_t where, void *stream);
 int cntt_prime64_normalize_batch(const cntt_plan64_t *plan, uint64_t *values, size_t batch, cntt_mem_t where, void *stream);
 int cntt_prime64_mul_accumulate_batch(const cntt_plan64_t *plan, uint64_t *acc, const uint64_t *lhs, const uint64_t *rhs, size_t batch, cntt_mem_t where, void *stream);
+/* Fused lhs <- inv(mul_assign_normalize(fwd(lhs), rhs_ntt)): the composition a caller of the reference writes as
+ * plan.fwd(a); plan.mul_assign_normalize(a, b_ntt); plan.inv(a)  (examples/mul_poly_prime.rs, src/prime64.rs:1254-1266),
+ * i.e. the negacyclic product of lhs with the polynomial whose forward transform is rhs_ntt, in one pass over HBM
+ * for n <= 1024 (three launches otherwise).  Same values as the three separate calls. */
+int cntt_prime64_mul_ntt_batch(const cntt_plan64_t *plan, uint64_t *lhs, const uint64_t *rhs_ntt, size_t batch, cntt_mem_t where, void *stream);
 
 /* ===================================================================================== */
 /* prime32::Plan  (src/prime32.rs:601-616)                                                */
@@ -119,6 +124,7 @@ int cntt_prime32_inv_batch(const cntt_plan32_t *plan, uint32_t *bufs, size_t bat
 int cntt_prime32_mul_assign_normalize_batch(const cntt_plan32_t *plan, uint32_t *lhs, const uint32_t *rhs, size_t batch, cntt_mem_t where, void *stream);
 int cntt_prime32_normalize_batch(const cntt_plan32_t *plan, uint32_t *values, size_t batch, cntt_mem_t where, void *stream);
 int cntt_prime32_mul_accumulate_batch(const cntt_plan32_t *plan, uint32_t *acc, const uint32_t *lhs, const uint32_t *rhs, size_t batch, cntt_mem_t where, void *stream);
+int cntt_prime32_mul_ntt_batch(const cntt_plan32_t *plan, uint32_t *lhs, const uint32_t *rhs_ntt, size_t batch, cntt_mem_t where, void *stream); /* see cntt_prime64_mul_ntt_batch */
 
 /* ===================================================================================== */
 /* native / native_binary plans                                                          */
@@ -179,7 +185,7 @@ int cntt_native_reserve(const cntt_native_t *plan, size_t batch);
 int cntt_fill_uniform_u64(uint64_t *dst, size_t count, uint64_t bound, uint64_t seed, void *stream);
 int cntt_fill_uniform_u32(uint32_t *dst, size_t count, uint32_t bound, uint64_t seed, void *stream);
 /* HIP-event timing on the stream the kernels run on (bench.py roofline leg): elapsed milliseconds
- * of `reps` back-to-back launches of one batched transform. op: 0 fwd, 1 inv, 2 mul_assign_normalize */
+ * of `reps` back-to-back launches of one batched operation. op: 0 fwd, 1 inv, 2 mul_assign_normalize, 5 mul_ntt */
 int cntt_prime64_time_batch(const cntt_plan64_t *plan, int op, uint64_t *bufs, const uint64_t *rhs, size_t batch, int reps, void *stream, float *ms_out);
 int cntt_prime32_time_batch(const cntt_plan32_t *plan, int op, uint32_t *bufs, const uint32_t *rhs, size_t batch, int reps, void *stream, float *ms_out);
 

@@ -226,6 +226,34 @@ def test_test_product_property(oracle, plans):
                 assert np.array_equal(prod, conv), (bits, p, n)
 
 
+@pytest.mark.parametrize("bits,n,p", [(64, 32, P62), (64, 64, P62), (64, 256, P62), (64, 1024, P62), (64, 2048, P62),
+                                      (64, 1024, 9223372036853661697), (64, 512, 18446744069414584321),
+                                      (64, 1024, 18446744073707716609), (64, 16, P62),
+                                      (32, 64, 1062862849), (32, 1024, 1062862849), (32, 1024, 2147352577),
+                                      (32, 512, 4293918721), (32, 4096, 1062862849), (32, 32, 1073479681)])
+def test_fused_mul_ntt_equals_three_calls(oracle, plans, oplans, bits, n, p):
+    """cntt_prime*_mul_ntt_batch == fwd; mul_assign_normalize; inv (src/prime64.rs:1254-1266), ragged batches,
+    fused kernel (n <= 1024) and the three-launch fallback."""
+    plan, ref = plans(bits, n, p), oplans(bits, n, p)
+    for batch in (1, 13, 301):
+        a = oracle.fill_uniform(batch * n, p, 31 + batch, bits)
+        b = oracle.fill_uniform(batch * n, p, 97 + batch, bits)
+        want, bn = a.copy(), b.copy()
+        ref.fwd_batch(bn, 4)
+        ref.fwd_batch(want, 4)
+        ref.mul_assign_normalize(want, bn)
+        ref.inv_batch(want, 4)
+        da = to_dev(a)
+        plan.mul_ntt_batch(da, to_dev(bn))
+        got = to_host(da, plan.dtype)
+        bad = np.nonzero(got != want)[0]
+        assert bad.size == 0, "bits=%d n=%d p=%d batch=%d: %d mismatches, first at %d" % (bits, n, p, batch, bad.size,
+                                                                                         bad[0])
+        # and it is the negacyclic product of a and b
+        if n <= 256 and batch == 1:
+            assert np.array_equal(got, oracle.negacyclic_convolution(n, p, a, b, bits))
+
+
 NATIVE = {"native32_plan32": native32.Plan32, "native64_plan32": native64.Plan32,
           "native128_plan32": native128.Plan32, "native_binary32_plan32": native_binary32.Plan32,
           "native_binary64_plan32": native_binary64.Plan32, "native_binary128_plan32": native_binary128.Plan32,

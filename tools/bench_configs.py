@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Secondary measurements (not the driver's bench line): the other BASELINE.json configs and the
+prime32 path, at steady-state clocks, as JSON lines with roofline fractions on SURVEY 8(d) byte counts."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import concrete_ntt_amd as cntt  # noqa: E402
+from concrete_ntt_amd import native64, native_binary64, prime32, prime64  # noqa: E402
+
+P62, P30 = 4611686018427322369, 1062862849
+PEAK = 8000.0
+
+
+def ramp(fn, seconds=1.5):
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize()
+
+
+def timed(fn, reps):
+    ramp(fn)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps  # ms
+
+
+def emit(name, ms, units, unit, bytes_):
+    gbs = bytes_ / (ms * 1e-3) / 1e9
+    print(json.dumps({"case": name, "ms": round(ms, 4), "rate": units / (ms * 1e-3), "unit": unit,
+                      "algorithmic_GBps": round(gbs, 1), "hbm_frac": round(gbs / PEAK, 4)}), flush=True)
+
+
+def prime_case(mod, bits, n, p, batch, tag):
+    plan = mod.Plan.try_new(n, p)
+    dt = torch.int64 if bits == 64 else torch.int32
+    a = torch.empty(batch * n, dtype=dt, device="cuda")
+    cntt.fill_uniform(a, p, 1234)
+    by = 2 * n * (bits // 8) * batch
+    emit("%s fwd N=%d batch=%d" % (tag, n, batch), timed(lambda: plan.fwd_batch(a), 20), batch, "NTT/s", by)
+    emit("%s inv N=%d batch=%d" % (tag, n, batch), timed(lambda: plan.inv_batch(a), 20), batch, "NTT/s", by)
+    b = torch.empty_like(a)
+    cntt.fill_uniform(b, p, 99)
+    emit("%s mul_ntt (fwd+pointwise+inv) N=%d batch=%d" % (tag, n, batch), timed(lambda: plan.mul_ntt_batch(a, b), 10),
+         2 * batch, "NTT/s", 2 * by)
+    emit("%s mul_assign_normalize N=%d batch=%d" % (tag, n, batch), timed(lambda: plan.mul_assign_normalize_batch(a, b), 20),
+         batch, "poly/s", 3 * n * (bits // 8) * batch)
+
+
+def native_case(cls, n, batch, tag, binary):
+    plan = cls.try_new(n)
+    lhs = torch.empty(batch * n, dtype=torch.int64, device="cuda")
+    rhs = torch.empty(batch * n, dtype=torch.int64, device="cuda")
+    prod = torch.empty(batch * n, dtype=torch.int64, device="cuda")
+    cntt.fill_uniform(lhs, 0, 5)
+    cntt.fill_uniform(rhs, 0, 6)
+    if binary:
+        rhs &= 1
+    plan.reserve(batch)
+    ms = timed(lambda: plan.negacyclic_polymul_batch(prod, lhs, rhs), 5)
+    emit("%s negacyclic_polymul N=%d batch=%d" % (tag, n, batch), ms, batch, "polymul/s", 3 * n * 8 * batch)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["p64", "p32", "c4", "c3", "c5"]
+    if "p64" in which:
+        prime_case(prime64, 64, 1024, P62, 65536, "prime64 (C2)")
+    if "p32" in which:
+        prime_case(prime32, 32, 1024, P30, 131072, "prime32")
+        prime_case(prime32, 32, 4096, P30, 32768, "prime32")
+    if "c4" in which:
+        prime_case(prime64, 64, 16384, P62, 4096, "prime64 (C4 shard slice)")
+        prime_case(prime64, 64, 4096, P62, 16384, "prime64")
+    if "c3" in which:
+        native_case(native64.Plan32, 4096, 16384, "native64::Plan32 (C3)", False)
+    if "c5" in which:
+        native_case(native_binary64.Plan32, 2048, 65536, "native_binary64::Plan32 (C5)", True)

@@ -42,7 +42,7 @@ for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
         for r in rows:
             agg[r.get("Kernel_Name", "?")][r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, cs in agg.items():
-            if "ntt_kernel" not in k and "pointwise" not in k:
+            if "ntt_kernel" not in k and "pointwise" not in k and "mul_kernel" not in k and "split" not in k and "crt" not in k:
                 continue
             print(short(k))
             for c, v in cs.items():
