@@ -146,10 +146,16 @@ def main():
     fwd_ms = plan.time_batch(0, a, reps=reps) / reps
     inv_ms = plan.time_batch(1, a, reps=reps) / reps
     mul_ms = plan.time_batch(2, a, rhs=b, reps=reps) / reps
-    alg_bytes = 2 * N * 8 * batch                     # read once + write once per transform
-    # the fused step kernel: read lhs, read rhs_ntt, write lhs = 3*N*8 bytes per polynomial, 2 transforms inside
-    fused_bytes = 3 * N * 8 * batch
-    achieved = fused_bytes / (fused_ms * 1e-3) / 1e9
+    alg_bytes = 2 * N * 8 * batch                     # 2*N*sizeof(T) = 16384 B per transform
+    # Dominant kernel of the timed region = the fused step kernel: 2 transforms per polynomial per launch.
+    # roofline.achieved = per-transform algorithmic bytes x transforms per launch / launch time (the kernel
+    # itself moves only 3*N*8 bytes per polynomial -- read lhs, read rhs_ntt, write lhs -- which is what
+    # `traffic` reports from the rocprofv3 PMC passes).
+    fused_alg = 2 * alg_bytes
+    achieved = fused_alg / (fused_ms * 1e-3) / 1e9
+    # HBM bytes per launch measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes; FETCH_SIZE
+    # doubled on gfx950) for exactly this kernel and batch: profiles/r01_v3_rocprofv3_summary.txt
+    traffic = (2 * 524731.8 + 524288.0) * 1024 if batch == 65536 else None
 
     if rank == 0:
         units = world * 2 * batch * args.steps        # forward + inverse transforms, all ranks
@@ -169,10 +175,10 @@ def main():
             "unfused_value": units / unfused, "unfused_ms_per_step": 1e3 * unfused / args.steps,
             "roofline": {"bound": "hbm", "kernel": "mul_kernel_wp<u64, LOGN=10, lazy> (fwd + pointwise + inv fused)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes_per_launch": fused_bytes, "avg_launch_ms": fused_ms,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": fused_alg, "avg_launch_ms": fused_ms,
                          "transforms_per_launch": 2 * batch,
-                         "equivalent_unfused_frac": 2 * alg_bytes / (fused_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "moved_bytes_frac": 3 * N * 8 * batch / (fused_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "fwd_kernel_ms": fwd_ms, "fwd_frac": alg_bytes / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "inv_kernel_ms": inv_ms, "inv_frac": alg_bytes / (inv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "pointwise_kernel_ms": mul_ms,
