@@ -67,6 +67,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=65536, help="polynomials per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL, one rank per GPU) is what the driver uses; gloo lets several ranks share one "
+                         "GPU to rehearse the multi-process path on a 1-GPU box")
     ap.add_argument("--ramp-seconds", type=float, default=2.0,
                     help="untimed back-to-back steps before the W warm-up steps, so that the timed region "
                          "runs at the steady-state DVFS clock instead of inside the ramp from idle")
@@ -81,12 +84,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    ndev = torch.cuda.device_count()
+    if args.dist_backend == "gloo":
+        local_rank = local_rank % max(ndev, 1)   # rehearsal mode: ranks may share a GPU
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo")
 
     batch = args.batch
     plan = prime64.Plan.try_new(N, P62)
@@ -128,7 +137,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
