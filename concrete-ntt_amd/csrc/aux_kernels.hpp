@@ -192,6 +192,8 @@ struct CrtArgs {
     uint64_t Mmod[5][5];         // Mmod[g][h] = M[h] mod M[g]            (h < g)
     uint64_t Mmod_shoup[5][5];   // Shoup companions
     uint64_t prefix_lo[6], prefix_hi[6];  // prefix[g] = M_0 ... M_{g-1} mod 2^128 (prefix[ngroups] = full product)
+    uint32_t inv_shoup32[5];     // 32-bit Shoup companions, used when every digit modulus is one 30-bit prime
+    uint32_t Mmod_shoup32[5][5];
 };
 
 // a * b mod m via Shoup (b < m < 2^63, a < 2^64): canonical
@@ -223,40 +225,57 @@ __device__ __forceinline__ u128d sub128(u128d a, u128d b) {
     return r;
 }
 
-template <class W, class R>
+// a * b mod m for 30-bit m via Shoup (any 32-bit a): canonical
+__device__ __forceinline__ uint32_t shoup_mulmod32(uint32_t a, uint32_t b, uint32_t b_shoup, uint32_t m) {
+    const uint32_t r = a * b - __umulhi(a, b_shoup) * m;
+    return umin<uint32_t>(r, r - m);
+}
+
+// NG digits; bit g of PAIRS set <=> digit g is a pair of primes.  Everything indexed by g / h is unrolled.
+template <class W, class R, int NG, uint32_t PAIRS>
 __global__ __launch_bounds__(256) void crt_kernel(W *__restrict__ value, CrtArgs A, size_t count) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
+    constexpr bool ALL32 = (PAIRS == 0u) && (sizeof(R) == 4);  // every digit modulus is a single 30-bit prime
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
-        uint64_t rg[5];
+        uint64_t rg[NG];
 #pragma unroll
-        for (int g = 0; g < 5; ++g) {
-            if (g < A.ngroups) {
-                const uint64_t va = reinterpret_cast<const R *>(A.res[A.ga[g]])[i];
-                if (A.gb[g] >= 0) {
-                    // v_b = (m_b - v_a) * P_a^-1 mod P_b ; group residue = v_a + v_b * P_a  (src/native64.rs:98-107)
-                    const uint64_t pa = A.prime[A.ga[g]], pb = A.prime[A.gb[g]];
-                    const uint64_t mb = reinterpret_cast<const R *>(A.res[A.gb[g]])[i];
-                    // Shoup product by the constant P_a^-1 (any 32-bit operand), then one conditional subtraction
-                    const uint32_t pb32 = (uint32_t)pb;
-                    const uint32_t d = (uint32_t)(2 * pb + mb - va);  // < 3 * 2^30
-                    const uint32_t t = d * (uint32_t)A.pair_inv[g] - __umulhi(d, A.pair_inv_shoup[g]) * pb32;
-                    const uint64_t vb = umin<uint32_t>(t, t - pb32);
-                    rg[g] = va + vb * pa;
-                } else {
-                    rg[g] = va;
-                }
+        for (int g = 0; g < NG; ++g) {
+            const uint64_t va = reinterpret_cast<const R *>(A.res[A.ga[g]])[i];
+            if (((PAIRS >> g) & 1u) != 0u) {  // compile-time after unrolling
+                // v_b = (m_b - v_a) * P_a^-1 mod P_b ; group residue = v_a + v_b * P_a  (src/native64.rs:98-107)
+                const uint64_t pa = A.prime[A.ga[g]], pb = A.prime[A.gb[g]];
+                const uint64_t mb = reinterpret_cast<const R *>(A.res[A.gb[g]])[i];
+                const uint32_t d = (uint32_t)(2 * pb + mb - va);  // < 3 * 2^30
+                const uint64_t vb = shoup_mulmod32(d, (uint32_t)A.pair_inv[g], A.pair_inv_shoup[g], (uint32_t)pb);
+                rg[g] = va + vb * pa;
+            } else {
+                rg[g] = va;
             }
         }
-        // digits
-        uint64_t v[5];
+        // mixed-radix digits: v_g = (r_g - (v_0 + M_0 (v_1 + M_1 (...)))) * inv_g mod M_g
+        uint64_t v[NG];
         v[0] = rg[0];
 #pragma unroll
-        for (int g = 1; g < 5; ++g) {
-            if (g < A.ngroups) {
+        for (int g = 1; g < NG; ++g) {
+            if constexpr (ALL32) {
+                const uint32_t m = (uint32_t)A.M[g];
+                uint32_t acc = (uint32_t)v[g - 1];  // digits are < 2^30 < 2m: one conditional subtraction canonicalises
+                acc = umin<uint32_t>(acc, acc - m);
+#pragma unroll
+                for (int h = g - 2; h >= 0; --h) {
+                    uint32_t t = shoup_mulmod32(acc, (uint32_t)A.Mmod[g][h], A.Mmod_shoup32[g][h], m);
+                    uint32_t vh = (uint32_t)v[h];
+                    vh = umin<uint32_t>(vh, vh - m);
+                    t += vh;
+                    acc = umin<uint32_t>(t, t - m);
+                }
+                const uint32_t rr = (uint32_t)rg[g];
+                const uint32_t d = rr - acc + m;  // in (0, 2m)
+                v[g] = shoup_mulmod32(d, (uint32_t)A.inv[g], A.inv_shoup32[g], m);
+            } else {
                 const uint64_t m = A.M[g];
-                // acc = (v_0 + M_0 (v_1 + M_1 (... v_{g-1}))) mod M[g], Horner from the top digit
                 uint64_t acc = v[g - 1];
-                if (acc >= m) acc %= m;
+                if (acc >= m) acc %= m;  // never taken for the reference's ascending moduli; kept for safety
 #pragma unroll
                 for (int h = g - 2; h >= 0; --h) {
                     uint64_t t = shoup_mulmod(acc, A.Mmod[g][h], A.Mmod_shoup[g][h], m);
@@ -271,19 +290,11 @@ __global__ __launch_bounds__(256) void crt_kernel(W *__restrict__ value, CrtArgs
                 v[g] = shoup_mulmod(d, A.inv[g], A.inv_shoup[g], m);
             }
         }
-        uint64_t vtop = v[0], mtop = A.M[0];
-#pragma unroll
-        for (int g = 1; g < 5; ++g)
-            if (g == A.ngroups - 1) {
-                vtop = v[g];
-                mtop = A.M[g];
-            }
-        const bool sign = vtop > (mtop / 2);
+        const bool sign = v[NG - 1] > (A.M[NG - 1] / 2);  // centred lift decided by the TOP digit
         u128d pos = {v[0], 0};
 #pragma unroll
-        for (int g = 1; g < 5; ++g)
-            if (g < A.ngroups) pos = add128(pos, mul_64x128(v[g], A.prefix_lo[g], A.prefix_hi[g]));
-        const u128d full = {A.prefix_lo[A.ngroups], A.prefix_hi[A.ngroups]};
+        for (int g = 1; g < NG; ++g) pos = add128(pos, mul_64x128(v[g], A.prefix_lo[g], A.prefix_hi[g]));
+        const u128d full = {A.prefix_lo[NG], A.prefix_hi[NG]};
         const u128d out = sign ? sub128(pos, full) : pos;
         if constexpr (sizeof(W) == 16) {
             reinterpret_cast<uint64_t *>(value)[2 * i] = out.lo;

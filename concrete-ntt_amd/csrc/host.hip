@@ -564,9 +564,11 @@ static void build_crt_args(cntt_native *pl) {
             for (int h = 0; h < g; ++h) pm = host::mulmod(pm, M[(size_t)h] % m, m);
             A.inv[g] = host::powmod(pm, phi - 1, m);
             A.inv_shoup[g] = (uint64_t)((((u128)A.inv[g]) << 64) / m);
+            A.inv_shoup32[g] = (m >> 32) == 0 ? (uint32_t)((A.inv[g] << 32) / m) : 0u;
             for (int h = 0; h < g; ++h) {
                 A.Mmod[g][h] = M[(size_t)h] % m;
                 A.Mmod_shoup[g][h] = (uint64_t)((((u128)A.Mmod[g][h]) << 64) / m);
+                A.Mmod_shoup32[g][h] = (m >> 32) == 0 ? (uint32_t)((A.Mmod[g][h] << 32) / m) : 0u;
             }
         }
         prefix *= (u128)m;  // wrapping mod 2^128, as src/lib.rs:592-595
@@ -664,22 +666,25 @@ static int native_split_device(const cntt_native *pl, const void *value, void *c
     HIP_TRY(hipGetLastError());
     return CNTT_OK;
 }
+template <class W, class R, int NG, uint32_t PAIRS>
+static void launch_crt(void *value, const CrtArgs &A, size_t count, hipStream_t st) {
+    hipLaunchKernelGGL((crt_kernel<W, R, NG, PAIRS>), dim3(ew_grid(count)), dim3(256), 0, st, (W *)value, A, count);
+}
 static int native_crt_device(const cntt_native *pl, void *value, void *const *res, size_t count, hipStream_t st) {
     CrtArgs A = pl->crt;
     for (int i = 0; i < A.k; ++i) A.res[i] = res[i];
-    const dim3 g(ew_grid(count)), b(256);
-    if (pl->info.is52) {
-        if (pl->info.word == 4)
-            hipLaunchKernelGGL((crt_kernel<uint32_t, uint64_t>), g, b, 0, st, (uint32_t *)value, A, count);
-        else
-            hipLaunchKernelGGL((crt_kernel<uint64_t, uint64_t>), g, b, 0, st, (uint64_t *)value, A, count);
-    } else {
-        if (pl->info.word == 4)
-            hipLaunchKernelGGL((crt_kernel<uint32_t, uint32_t>), g, b, 0, st, (uint32_t *)value, A, count);
-        else if (pl->info.word == 8)
-            hipLaunchKernelGGL((crt_kernel<uint64_t, uint32_t>), g, b, 0, st, (uint64_t *)value, A, count);
-        else
-            hipLaunchKernelGGL((crt_kernel<W128, uint32_t>), g, b, 0, st, (W128 *)value, A, count);
+    switch (pl->kind) {  // digit structure of each reference plan (NATIVE_KINDS)
+    case CNTT_NATIVE32_PLAN32: launch_crt<uint32_t, uint32_t, 3, 0u>(value, A, count, st); break;
+    case CNTT_NATIVE64_PLAN32: launch_crt<uint64_t, uint32_t, 3, 0b110u>(value, A, count, st); break;
+    case CNTT_NATIVE128_PLAN32: launch_crt<W128, uint32_t, 5, 0b11111u>(value, A, count, st); break;
+    case CNTT_NATIVE_BINARY32_PLAN32: launch_crt<uint32_t, uint32_t, 2, 0u>(value, A, count, st); break;
+    case CNTT_NATIVE_BINARY64_PLAN32: launch_crt<uint64_t, uint32_t, 3, 0u>(value, A, count, st); break;
+    case CNTT_NATIVE_BINARY128_PLAN32: launch_crt<W128, uint32_t, 3, 0b110u>(value, A, count, st); break;
+    case CNTT_NATIVE32_PLAN52: launch_crt<uint32_t, uint64_t, 2, 0u>(value, A, count, st); break;
+    case CNTT_NATIVE64_PLAN52: launch_crt<uint64_t, uint64_t, 3, 0u>(value, A, count, st); break;
+    case CNTT_NATIVE_BINARY32_PLAN52: launch_crt<uint32_t, uint64_t, 1, 0u>(value, A, count, st); break;
+    case CNTT_NATIVE_BINARY64_PLAN52: launch_crt<uint64_t, uint64_t, 2, 0u>(value, A, count, st); break;
+    default: return fail(CNTT_EINVAL, "unknown native plan kind");
     }
     HIP_TRY(hipGetLastError());
     return CNTT_OK;
