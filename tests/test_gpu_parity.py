@@ -429,6 +429,10 @@ def test_c2_full_size_properties(oracle, plans, oplans):
         assert np.array_equal(to_host(fa[s * n:(s + 1) * n], np.uint64), x), s
     # canonical outputs
     assert int(fa.max()) < P62 and int(fa.min()) >= 0
+    # the fused kernel (cntt_prime64_mul_ntt_batch) gives the same 64 Mi words as the three launches
+    c = a0.clone()
+    plan.mul_ntt_batch(c, b)
+    assert torch.equal(c, fa)
 
 
 def test_c4_shard_size_properties(oracle, plans, oplans):
