@@ -1,13 +1,14 @@
 """MI355X-native batched negacyclic NTT engine with the API surface of zama-ai/concrete-ntt.
 
 Module layout mirrors the reference crate (src/lib.rs:88-110): prime32, prime64, native32, native64,
-native128, native_binary32, native_binary64, native_binary128.  Every transform runs in hand-written
+native128, native_binary32, native_binary64, native_binary128, product.  Every transform runs in hand-written
 HIP kernels (csrc/) behind the C ABI of include/cntt.h; there is no CPU compute path.
 """
 from . import _lib
 from ._lib import DeviceError, Panic, build, lib  # noqa: F401
 from . import prime32, prime64  # noqa: F401
 from . import native32, native64, native128, native_binary32, native_binary64, native_binary128  # noqa: F401
+from . import product  # noqa: F401
 
 
 def device_count():

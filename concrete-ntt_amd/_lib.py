@@ -100,6 +100,28 @@ def lib():
         "cntt_native_inv_batch": (c_int, [c_vp, c_vp, c_vp, c_sz, c_int, c_vp]),
         "cntt_native_negacyclic_polymul_batch": (c_int, [c_vp, c_vp, c_vp, c_vp, c_sz, c_int, c_vp]),
         "cntt_native_reserve": (c_int, [c_vp, c_sz]),
+        "cntt_product_plan_new": (c_int, [c_sz, c_u64, c_vp, c_sz, c_vp]),
+        "cntt_product_plan_clone": (c_vp, [c_vp]),
+        "cntt_product_plan_free": (None, [c_vp]),
+        "cntt_product_ntt_size": (c_sz, [c_vp]),
+        "cntt_product_modulus": (c_u64, [c_vp]),
+        "cntt_product_ntt_domain_len": (c_sz, [c_vp]),
+        "cntt_product_nprimes32": (c_int, [c_vp]),
+        "cntt_product_nprimes64": (c_int, [c_vp]),
+        "cntt_product_prime": (c_u64, [c_vp, c_int]),
+        "cntt_product_ntt32": (c_vp, [c_vp, c_int]),
+        "cntt_product_ntt64": (c_vp, [c_vp, c_int]),
+        "cntt_product_modular_inverses": (c_int, [c_vp, c_vp, c_sz]),
+        "cntt_product_fwd": (c_int, [c_vp, c_vp, c_sz, c_vp, c_sz, c_int, c_u64]),
+        "cntt_product_inv": (c_int, [c_vp, c_vp, c_sz, c_vp, c_sz, c_int]),
+        "cntt_product_mul_assign_normalize": (c_int, [c_vp, c_vp, c_sz, c_vp, c_sz]),
+        "cntt_product_normalize": (c_int, [c_vp, c_vp, c_sz]),
+        "cntt_product_mul_accumulate": (c_int, [c_vp, c_vp, c_sz, c_vp, c_sz, c_vp, c_sz]),
+        "cntt_product_fwd_batch": (c_int, [c_vp, c_vp, c_vp, c_sz, c_int, c_u64, c_int, c_vp]),
+        "cntt_product_inv_batch": (c_int, [c_vp, c_vp, c_vp, c_sz, c_int, c_int, c_vp]),
+        "cntt_product_mul_assign_normalize_batch": (c_int, [c_vp, c_vp, c_vp, c_sz, c_int, c_vp]),
+        "cntt_product_normalize_batch": (c_int, [c_vp, c_vp, c_sz, c_int, c_vp]),
+        "cntt_product_mul_accumulate_batch": (c_int, [c_vp, c_vp, c_vp, c_vp, c_sz, c_int, c_vp]),
         "cntt_fill_uniform_u64": (c_int, [c_vp, c_sz, c_u64, c_u64, c_vp]),
         "cntt_fill_uniform_u32": (c_int, [c_vp, c_sz, c_u32, c_u64, c_vp]),
     }

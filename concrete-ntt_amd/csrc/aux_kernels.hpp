@@ -305,4 +305,133 @@ __global__ __launch_bounds__(256) void crt_kernel(W *__restrict__ value, CrtArgs
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// product::Plan (src/product.rs): residue split of u64 coefficients and Garner recombination.
+// Batched NTT-domain layout: plane-major.  u32 plane k (k < n32) holds `count` = batch * n residues at
+// res32 + k * count; u64 plane k at res64 + k * count, where res64 = res32 + n32 * count u32 words.
+// With batch == 1 this is exactly the reference's layout (src/product.rs:261-270).
+// Both kernels are elementwise and HBM-bound: 8 B in, 4 B * n32 + 8 B * n64 out per coefficient.
+// ---------------------------------------------------------------------------------------------
+constexpr int PRODUCT_MAX_PRIMES = 8;  // distinct primes = 1 mod 64 with a product < 2^64: at most 7
+
+struct ProductArgs {
+    int n32, n64;
+    uint64_t modulus, bound;
+    uint64_t prime[PRODUCT_MAX_PRIMES];    // ascending: the n32 primes below 2^32 first (src/product.rs:183-184)
+    uint64_t barrett[PRODUCT_MAX_PRIMES];  // floor(2^64 / prime)
+    uint64_t inv[28], inv_shoup[28];       // pair (j, i < j) at j(j-1)/2 + i: prime[i]^-1 mod prime[j] (src/product.rs:207-229)
+};
+
+// x mod p for any odd p < 2^64, no division: q = floor(x * floor(2^64/p) / 2^64) >= floor(x/p) - 1
+__device__ __forceinline__ uint64_t barrett_rem(uint64_t x, uint64_t p, uint64_t m) {
+    uint64_t r = x - mulhi(x, m) * p;
+    r = r >= p ? r - p : r;
+    return r >= p ? r - p : r;
+}
+
+// MODE 0: FwdMode::Generic, `%` per prime (src/product.rs:323-355)
+// MODE 1: FwdMode::Bounded fast path of the u32x2 plan (src/product.rs:303-322), same select as the reference
+// MODE 2: single-prime plans: u64x1 copies, u32x1 truncates -- no reduction (src/product.rs:282-293)
+template <int MODE>
+__global__ __launch_bounds__(256) void product_split_kernel(uint32_t *__restrict__ res32, uint64_t *__restrict__ res64,
+                                                            const uint64_t *__restrict__ standard, ProductArgs A,
+                                                            size_t count) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t pairs = count / 2;  // n is even (src/product.rs:158)
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < pairs; i += stride) {
+        const ulonglong2 s = reinterpret_cast<const ulonglong2 *>(standard)[i];
+        if constexpr (MODE == 1) {
+            const uint32_t p0 = (uint32_t)A.prime[0], p1 = (uint32_t)A.prime[1], pu = (uint32_t)A.modulus;
+            const uint64_t half = A.modulus / 2;
+            const uint32_t sx = (uint32_t)s.x, sy = (uint32_t)s.y;
+            const bool posx = s.x < half, posy = s.y < half;
+            const uint32_t cx = pu - sx, cy = pu - sy;
+            reinterpret_cast<uint2 *>(res32)[i] = make_uint2(posx ? sx : p0 - cx, posy ? sy : p0 - cy);
+            reinterpret_cast<uint2 *>(res32 + count)[i] = make_uint2(posx ? sx : p1 - cx, posy ? sy : p1 - cy);
+        } else if constexpr (MODE == 2) {
+            if (A.n32 == 1) reinterpret_cast<uint2 *>(res32)[i] = make_uint2((uint32_t)s.x, (uint32_t)s.y);
+            else reinterpret_cast<ulonglong2 *>(res64)[i] = s;
+        } else {
+            for (int k = 0; k < A.n32; ++k)
+                reinterpret_cast<uint2 *>(res32 + (size_t)k * count)[i] =
+                    make_uint2((uint32_t)barrett_rem(s.x, A.prime[k], A.barrett[k]),
+                               (uint32_t)barrett_rem(s.y, A.prime[k], A.barrett[k]));
+            for (int k = 0; k < A.n64; ++k) {
+                const uint64_t p = A.prime[A.n32 + k], m = A.barrett[A.n32 + k];
+                ulonglong2 r;
+                r.x = barrett_rem(s.x, p, m);
+                r.y = barrett_rem(s.y, p, m);
+                reinterpret_cast<ulonglong2 *>(res64 + (size_t)k * count)[i] = r;
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ uint64_t add_mod_u64(uint64_t m, uint64_t a, uint64_t b) {  // src/product.rs:85-92
+    const uint64_t sum = a + b;
+    return (sum >= m || sum < a) ? sum - m : sum;
+}
+__device__ __forceinline__ uint32_t add_mod_u32(uint32_t m, uint32_t a, uint32_t b) {  // src/product.rs:107-114
+    const uint32_t sum = a + b;
+    return (sum >= m || sum < a) ? sum - m : sum;
+}
+
+// Garner (Knuth 4.3.2) over K residues of one coefficient, then Horner: src/product.rs:791-879 (and its
+// u64x1 / u32x1 / u32x2 special cases :386-789, which produce the same digits).
+// ACC 0: InvMode::Replace; 1: Accumulate with add_mod_u64(modulus, ..); 2: Accumulate of the u32x1 plan, which
+// the reference performs in u32 on the truncated `standard` (src/product.rs:408-413).
+template <int K> __device__ __forceinline__ uint64_t garner(const uint64_t (&u)[K], const ProductArgs &A) {
+    uint64_t v[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        uint64_t x = u[j];
+        const uint64_t pj = A.prime[j];
+#pragma unroll
+        for (int i = 0; i < j; ++i) {
+            const uint64_t d = x >= v[i] ? x - v[i] : x - v[i] + pj;  // sub_mod: v[i] < prime[i] < prime[j]
+            x = shoup_mulmod(d, A.inv[j * (j - 1) / 2 + i], A.inv_shoup[j * (j - 1) / 2 + i], pj);
+        }
+        v[j] = x;
+    }
+    uint64_t acc = 0;
+#pragma unroll
+    for (int j = K - 1; j >= 0; --j) acc = acc * A.prime[j] + v[j];
+    return acc;
+}
+
+template <int K, int ACC>
+__global__ __launch_bounds__(256) void product_crt_kernel(uint64_t *__restrict__ standard, const uint32_t *__restrict__ res32,
+                                                          const uint64_t *__restrict__ res64, ProductArgs A, size_t count) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t pairs = count / 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < pairs; i += stride) {
+        uint64_t ux[K], uy[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            if (j < A.n32) {
+                const uint2 r = reinterpret_cast<const uint2 *>(res32 + (size_t)j * count)[i];
+                ux[j] = r.x;
+                uy[j] = r.y;
+            } else {
+                const ulonglong2 r = reinterpret_cast<const ulonglong2 *>(res64 + (size_t)(j - A.n32) * count)[i];
+                ux[j] = r.x;
+                uy[j] = r.y;
+            }
+        }
+        ulonglong2 out;
+        out.x = garner<K>(ux, A);
+        out.y = garner<K>(uy, A);
+        if constexpr (ACC == 1) {
+            const ulonglong2 s = reinterpret_cast<const ulonglong2 *>(standard)[i];
+            out.x = add_mod_u64(A.modulus, s.x, out.x);
+            out.y = add_mod_u64(A.modulus, s.y, out.y);
+        } else if constexpr (ACC == 2) {
+            const ulonglong2 s = reinterpret_cast<const ulonglong2 *>(standard)[i];
+            out.x = add_mod_u32((uint32_t)A.modulus, (uint32_t)s.x, (uint32_t)out.x);
+            out.y = add_mod_u32((uint32_t)A.modulus, (uint32_t)s.y, (uint32_t)out.y);
+        }
+        reinterpret_cast<ulonglong2 *>(standard)[i] = out;
+    }
+}
+
 }  // namespace cntt

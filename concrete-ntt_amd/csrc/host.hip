@@ -848,3 +848,294 @@ extern "C" int cntt_native_negacyclic_polymul(const cntt_native_t *pl, void *pro
     if (pn != pl->n) return fail(CNTT_ELEN, "assert_eq!(buf.len(), ntt_size): %zu != %zu", pn, pl->n);
     return cntt_native_negacyclic_polymul_batch(pl, prod, lhs, rhs, 1, CNTT_MEM_HOST, nullptr);
 }
+
+// ---------------------------------------------------------------------------------------------
+// product::Plan  (src/product.rs:139-967)
+// ---------------------------------------------------------------------------------------------
+struct cntt_product {
+    size_t n = 0;
+    uint64_t modulus = 0;
+    std::vector<uint64_t> primes;  // ascending, 1s removed
+    std::vector<std::shared_ptr<cntt_plan32>> p32;
+    std::vector<std::shared_ptr<cntt_plan64>> p64;
+    std::vector<uint64_t> modular_inverses;  // src/product.rs:207-229
+    ProductArgs args{};
+    size_t len32() const { return (n / 2) * p32.size(); }          // ntt_domain_len_u32 src/product.rs:261-263
+    size_t domain_len() const { return len32() + n * p64.size(); } // ntt_domain_len     src/product.rs:268-270
+};
+
+// Plan::try_new src/product.rs:153-247
+extern "C" int cntt_product_plan_new(size_t n, uint64_t modulus, const uint64_t *factors, size_t nfactors,
+                                     cntt_product_t **out) {
+    if (!out) return fail(CNTT_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (nfactors && !factors) return fail(CNTT_EINVAL, "factors is NULL");
+    if (n % 2 != 0) return CNTT_NONE;
+    std::vector<uint64_t> primes(factors, factors + nfactors);
+    std::sort(primes.begin(), primes.end());
+    uint64_t prev = 0;
+    for (uint64_t f : primes) {  // zero or repeated factor: src/product.rs:163-169
+        if (f == prev) return CNTT_NONE;
+        prev = f;
+    }
+    primes.erase(primes.begin(), std::find_if(primes.begin(), primes.end(), [](uint64_t f) { return f != 1; }));
+    uint64_t prod = 1;
+    for (uint64_t f : primes) {  // checked_mul: src/product.rs:173-177
+        const u128 w = (u128)prod * f;
+        if (w >> 64) return CNTT_NONE;
+        prod = (uint64_t)w;
+    }
+    if (prod != modulus) return CNTT_NONE;
+    // distinct primes = 1 mod 2n >= 65 whose product fits u64: never more than 7; anything longer has a
+    // non-prime factor and try_new of that factor would return None anyway
+    if (primes.size() >= (size_t)PRODUCT_MAX_PRIMES) return CNTT_NONE;
+    std::unique_ptr<cntt_product> pl(new (std::nothrow) cntt_product());
+    if (!pl) return fail(CNTT_ENOMEM, "out of memory");
+    pl->n = n;
+    pl->modulus = modulus;
+    pl->primes = primes;
+    for (uint64_t f : primes) {
+        if (f < ((uint64_t)1 << 32)) {
+            cntt_plan32 *sub = nullptr;
+            if (int rc = plan_new<uint32_t, cntt_plan32>(n, (uint32_t)f, &sub)) return rc;
+            pl->p32.emplace_back(sub);
+        } else {
+            cntt_plan64 *sub = nullptr;
+            if (int rc = plan_new<uint64_t, cntt_plan64>(n, f, &sub)) return rc;
+            pl->p64.emplace_back(sub);
+        }
+    }
+    ProductArgs &A = pl->args;
+    A.n32 = (int)pl->p32.size();
+    A.n64 = (int)pl->p64.size();
+    A.modulus = modulus;
+    for (size_t j = 0; j < primes.size(); ++j) {
+        A.prime[j] = primes[j];
+        A.barrett[j] = (uint64_t)((((u128)1) << 64) / primes[j]);
+        for (size_t i = 0; i < j; ++i) {  // every factor is prime here, so Fermat gives the Euclid inverse of :22-64
+            const uint64_t inv = host::powmod(primes[i] % primes[j], primes[j] - 2, primes[j]);
+            pl->modular_inverses.push_back(inv);
+            A.inv[j * (j - 1) / 2 + i] = inv;
+            A.inv_shoup[j * (j - 1) / 2 + i] = (uint64_t)((((u128)inv) << 64) / primes[j]);
+        }
+    }
+    *out = pl.release();
+    return CNTT_OK;
+}
+extern "C" cntt_product_t *cntt_product_plan_clone(const cntt_product_t *pl) {
+    return pl ? new (std::nothrow) cntt_product(*pl) : nullptr;  // prime plans are immutable and shared
+}
+extern "C" void cntt_product_plan_free(cntt_product_t *pl) { delete pl; }
+extern "C" size_t cntt_product_ntt_size(const cntt_product_t *pl) { return pl ? pl->n : 0; }
+extern "C" uint64_t cntt_product_modulus(const cntt_product_t *pl) { return pl ? pl->modulus : 0; }
+extern "C" size_t cntt_product_ntt_domain_len(const cntt_product_t *pl) { return pl ? pl->domain_len() : 0; }
+extern "C" int cntt_product_nprimes32(const cntt_product_t *pl) { return pl ? (int)pl->p32.size() : 0; }
+extern "C" int cntt_product_nprimes64(const cntt_product_t *pl) { return pl ? (int)pl->p64.size() : 0; }
+extern "C" uint64_t cntt_product_prime(const cntt_product_t *pl, int i) {
+    return (pl && i >= 0 && (size_t)i < pl->primes.size()) ? pl->primes[(size_t)i] : 0;
+}
+extern "C" const cntt_plan32_t *cntt_product_ntt32(const cntt_product_t *pl, int i) {
+    return (pl && i >= 0 && (size_t)i < pl->p32.size()) ? pl->p32[(size_t)i].get() : nullptr;
+}
+extern "C" const cntt_plan64_t *cntt_product_ntt64(const cntt_product_t *pl, int i) {
+    return (pl && i >= 0 && (size_t)i < pl->p64.size()) ? pl->p64[(size_t)i].get() : nullptr;
+}
+extern "C" int cntt_product_modular_inverses(const cntt_product_t *pl, uint64_t *out, size_t len) {
+    if (!pl || (!out && len)) return fail(CNTT_EINVAL, "NULL argument");
+    if (len != pl->modular_inverses.size()) return fail(CNTT_ELEN, "expected %zu inverses", pl->modular_inverses.size());
+    std::copy(pl->modular_inverses.begin(), pl->modular_inverses.end(), out);
+    return CNTT_OK;
+}
+
+// plane-major device views of a batched NTT-domain buffer (see aux_kernels.hpp)
+struct ProductView {
+    uint32_t *r32;
+    uint64_t *r64;
+};
+static ProductView product_view(const cntt_product *pl, uint64_t *ntt, size_t batch) {
+    return {reinterpret_cast<uint32_t *>(ntt), ntt + pl->len32() * batch};
+}
+static int product_ntt_device(const cntt_product *pl, ProductView v, size_t batch, bool inv, hipStream_t st) {
+    const size_t count = batch * pl->n;
+    for (size_t k = 0; k < pl->p32.size(); ++k)
+        if (int rc = ntt_device<uint32_t>(pl->p32[k].get(), v.r32 + k * count, batch, inv, st)) return rc;
+    for (size_t k = 0; k < pl->p64.size(); ++k)
+        if (int rc = ntt_device<uint64_t>(pl->p64[k].get(), v.r64 + k * count, batch, inv, st)) return rc;
+    return CNTT_OK;
+}
+
+// Plan::fwd src/product.rs:273-357  (device pointers)
+static int product_fwd_device(const cntt_product *pl, uint64_t *ntt, const uint64_t *standard, size_t batch,
+                              bool bounded, uint64_t bound, hipStream_t st) {
+    const size_t count = batch * pl->n, k = pl->primes.size();
+    if (count == 0 || k == 0) return CNTT_OK;
+    const ProductView v = product_view(pl, ntt, batch);
+    ProductArgs A = pl->args;
+    A.bound = bound;
+    const dim3 grid(ew_grid(count / 2)), block(256);
+    if (k == 1)
+        hipLaunchKernelGGL((product_split_kernel<2>), grid, block, 0, st, v.r32, v.r64, standard, A, count);
+    else if (A.n32 == 2 && A.n64 == 0 && bounded && bound < A.prime[0] && bound < A.prime[1])
+        hipLaunchKernelGGL((product_split_kernel<1>), grid, block, 0, st, v.r32, v.r64, standard, A, count);
+    else
+        hipLaunchKernelGGL((product_split_kernel<0>), grid, block, 0, st, v.r32, v.r64, standard, A, count);
+    HIP_TRY(hipGetLastError());
+    return product_ntt_device(pl, v, batch, false, st);
+}
+
+template <int K>
+static void launch_product_crt(uint64_t *standard, ProductView v, const ProductArgs &A, size_t count, int acc,
+                               hipStream_t st) {
+    const dim3 grid(ew_grid(count / 2)), block(256);
+    if (acc == 0) hipLaunchKernelGGL((product_crt_kernel<K, 0>), grid, block, 0, st, standard, v.r32, v.r64, A, count);
+    else if (acc == 1) hipLaunchKernelGGL((product_crt_kernel<K, 1>), grid, block, 0, st, standard, v.r32, v.r64, A, count);
+    else hipLaunchKernelGGL((product_crt_kernel<K, 2>), grid, block, 0, st, standard, v.r32, v.r64, A, count);
+}
+
+// Plan::inv src/product.rs:360-879  (device pointers)
+static int product_inv_device(const cntt_product *pl, uint64_t *standard, uint64_t *ntt, size_t batch, bool accumulate,
+                              hipStream_t st) {
+    const size_t count = batch * pl->n, k = pl->primes.size();
+    if (count == 0) return CNTT_OK;
+    if (k == 0) {  // src/product.rs:378-384
+        if (!accumulate) HIP_TRY(hipMemsetAsync(standard, 0, count * 8, st));
+        return CNTT_OK;
+    }
+    const ProductView v = product_view(pl, ntt, batch);
+    if (int rc = product_ntt_device(pl, v, batch, true, st)) return rc;
+    const int acc = !accumulate ? 0 : (k == 1 && pl->p32.size() == 1 ? 2 : 1);
+    switch (k) {
+    case 1: launch_product_crt<1>(standard, v, pl->args, count, acc, st); break;
+    case 2: launch_product_crt<2>(standard, v, pl->args, count, acc, st); break;
+    case 3: launch_product_crt<3>(standard, v, pl->args, count, acc, st); break;
+    case 4: launch_product_crt<4>(standard, v, pl->args, count, acc, st); break;
+    case 5: launch_product_crt<5>(standard, v, pl->args, count, acc, st); break;
+    case 6: launch_product_crt<6>(standard, v, pl->args, count, acc, st); break;
+    default: launch_product_crt<7>(standard, v, pl->args, count, acc, st); break;
+    }
+    HIP_TRY(hipGetLastError());
+    return CNTT_OK;
+}
+
+// op 2 mul_assign_normalize, 3 normalize, 4 mul_accumulate, per prime on the plane-major layout: src/product.rs:885-966
+static int product_pointwise_device(const cntt_product *pl, int op, uint64_t *a, const uint64_t *b, const uint64_t *c,
+                                    size_t batch, hipStream_t st) {
+    const size_t count = batch * pl->n;
+    if (count == 0) return CNTT_OK;
+    const size_t off64 = pl->len32() * batch;
+    for (size_t k = 0; k < pl->p32.size() + pl->p64.size(); ++k) {
+        int rc;
+        if (k < pl->p32.size()) {
+            const cntt_plan32 *sub = pl->p32[k].get();
+            uint32_t *pa = reinterpret_cast<uint32_t *>(a) + k * count;
+            const uint32_t *pb = b ? reinterpret_cast<const uint32_t *>(b) + k * count : nullptr;
+            const uint32_t *pc = c ? reinterpret_cast<const uint32_t *>(c) + k * count : nullptr;
+            rc = op == 2   ? pointwise_device<uint32_t, PW_MUL_NORMALIZE>(sub, pa, pb, nullptr, count, st)
+                 : op == 3 ? pointwise_device<uint32_t, PW_NORMALIZE>(sub, pa, nullptr, nullptr, count, st)
+                           : pointwise_device<uint32_t, PW_MUL_ACCUMULATE>(sub, pa, pb, pc, count, st);
+        } else {
+            const size_t o = off64 + (k - pl->p32.size()) * count;
+            const cntt_plan64 *sub = pl->p64[k - pl->p32.size()].get();
+            rc = op == 2   ? pointwise_device<uint64_t, PW_MUL_NORMALIZE>(sub, a + o, b + o, nullptr, count, st)
+                 : op == 3 ? pointwise_device<uint64_t, PW_NORMALIZE>(sub, a + o, nullptr, nullptr, count, st)
+                           : pointwise_device<uint64_t, PW_MUL_ACCUMULATE>(sub, a + o, b + o, c + o, count, st);
+        }
+        if (rc) return rc;
+    }
+    return CNTT_OK;
+}
+
+// op: 0 fwd (a = ntt out, b = standard in), 1 inv (a = standard, b = ntt, both written),
+//     2 mul_assign_normalize (a lhs, b rhs), 3 normalize (a), 4 mul_accumulate (a acc, b lhs, c rhs)
+static int product_op(const cntt_product *pl, int op, uint64_t *a, uint64_t *b, const uint64_t *c, size_t batch, int mode,
+                      uint64_t bound, cntt_mem_t where, hipStream_t st) {
+    if (!pl) return fail(CNTT_EINVAL, "plan is NULL");
+    if (batch == 0) return CNTT_OK;
+    if (batch * pl->n >= ((size_t)1 << 40)) return fail(CNTT_EINVAL, "batch too large");
+    const size_t std_words = batch * pl->n, dom_words = batch * pl->domain_len();
+    const size_t aw = op == 1 ? std_words : dom_words, bw = op == 0 ? std_words : dom_words;
+    if ((!a && aw) || (op != 3 && !b && bw) || (op == 4 && !c && dom_words)) return fail(CNTT_EINVAL, "NULL buffer");
+    auto run = [&](uint64_t *da, uint64_t *db, const uint64_t *dc) -> int {
+        switch (op) {
+        case 0: return product_fwd_device(pl, da, db, batch, mode != 0, bound, st);
+        case 1: return product_inv_device(pl, da, db, batch, mode != 0, st);
+        default: return product_pointwise_device(pl, op, da, db, dc, batch, st);
+        }
+    };
+    if (where == CNTT_MEM_DEVICE) return run(a, b, c);
+    DevBuf da, db, dc;
+    if (int rc = da.alloc(aw * 8)) return rc;
+    if (op != 0 && !(op == 1 && mode == 0)) HIP_TRY(hipMemcpyAsync(da.p, a, aw * 8, hipMemcpyHostToDevice, st));
+    if (op != 3) {
+        if (int rc = db.alloc(bw * 8)) return rc;
+        HIP_TRY(hipMemcpyAsync(db.p, b, bw * 8, hipMemcpyHostToDevice, st));
+    }
+    if (op == 4) {
+        if (int rc = dc.alloc(dom_words * 8)) return rc;
+        HIP_TRY(hipMemcpyAsync(dc.p, c, dom_words * 8, hipMemcpyHostToDevice, st));
+    }
+    if (int rc = run((uint64_t *)da.p, (uint64_t *)db.p, (const uint64_t *)dc.p)) return rc;
+    if (!(op == 1 && mode != 0 && pl->primes.empty()) && aw) HIP_TRY(hipMemcpyAsync(a, da.p, aw * 8, hipMemcpyDeviceToHost, st));
+    // inv leaves the inverse-transformed residues in the caller's ntt buffer: src/product.rs:368-373
+    if (op == 1 && bw) HIP_TRY(hipMemcpyAsync(b, db.p, bw * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return CNTT_OK;
+}
+
+#define PRODUCT_LEN(have, want, what)                                                                          \
+    if ((have) != (want)) return fail(CNTT_ELEN, "assert_eq!(" what "): %zu != %zu", (size_t)(have), (size_t)(want))
+
+extern "C" int cntt_product_fwd(const cntt_product_t *pl, uint64_t *ntt, size_t ntt_len, const uint64_t *standard,
+                                size_t standard_len, cntt_fwd_mode_t mode, uint64_t bound) {
+    if (!pl) return fail(CNTT_EINVAL, "plan is NULL");
+    PRODUCT_LEN(standard_len, pl->n, "standard.len(), ntt_size");
+    PRODUCT_LEN(ntt_len, pl->domain_len(), "ntt.len(), ntt_domain_len");
+    return product_op(pl, 0, ntt, const_cast<uint64_t *>(standard), nullptr, 1, (int)mode, bound, CNTT_MEM_HOST, nullptr);
+}
+extern "C" int cntt_product_inv(const cntt_product_t *pl, uint64_t *standard, size_t standard_len, uint64_t *ntt,
+                                size_t ntt_len, cntt_inv_mode_t mode) {
+    if (!pl) return fail(CNTT_EINVAL, "plan is NULL");
+    PRODUCT_LEN(standard_len, pl->n, "standard.len(), ntt_size");
+    PRODUCT_LEN(ntt_len, pl->domain_len(), "ntt.len(), ntt_domain_len");
+    return product_op(pl, 1, standard, ntt, nullptr, 1, (int)mode, 0, CNTT_MEM_HOST, nullptr);
+}
+extern "C" int cntt_product_mul_assign_normalize(const cntt_product_t *pl, uint64_t *lhs, size_t lhs_len,
+                                                 const uint64_t *rhs, size_t rhs_len) {
+    if (!pl) return fail(CNTT_EINVAL, "plan is NULL");
+    PRODUCT_LEN(lhs_len, pl->domain_len(), "lhs.len(), ntt_domain_len");
+    PRODUCT_LEN(rhs_len, pl->domain_len(), "rhs.len(), ntt_domain_len");
+    return product_op(pl, 2, lhs, const_cast<uint64_t *>(rhs), nullptr, 1, 0, 0, CNTT_MEM_HOST, nullptr);
+}
+extern "C" int cntt_product_normalize(const cntt_product_t *pl, uint64_t *values, size_t len) {
+    if (!pl) return fail(CNTT_EINVAL, "plan is NULL");
+    PRODUCT_LEN(len, pl->domain_len(), "values.len(), ntt_domain_len");
+    return product_op(pl, 3, values, nullptr, nullptr, 1, 0, 0, CNTT_MEM_HOST, nullptr);
+}
+extern "C" int cntt_product_mul_accumulate(const cntt_product_t *pl, uint64_t *acc, size_t acc_len, const uint64_t *lhs,
+                                           size_t lhs_len, const uint64_t *rhs, size_t rhs_len) {
+    if (!pl) return fail(CNTT_EINVAL, "plan is NULL");
+    PRODUCT_LEN(lhs_len, pl->domain_len(), "lhs.len(), ntt_domain_len");
+    PRODUCT_LEN(rhs_len, pl->domain_len(), "rhs.len(), ntt_domain_len");
+    PRODUCT_LEN(acc_len, pl->domain_len(), "acc.len(), ntt_domain_len");
+    return product_op(pl, 4, acc, const_cast<uint64_t *>(lhs), rhs, 1, 0, 0, CNTT_MEM_HOST, nullptr);
+}
+extern "C" int cntt_product_fwd_batch(const cntt_product_t *pl, uint64_t *ntt, const uint64_t *standard, size_t batch,
+                                      cntt_fwd_mode_t mode, uint64_t bound, cntt_mem_t where, void *stream) {
+    return product_op(pl, 0, ntt, const_cast<uint64_t *>(standard), nullptr, batch, (int)mode, bound, where, (hipStream_t)stream);
+}
+extern "C" int cntt_product_inv_batch(const cntt_product_t *pl, uint64_t *standard, uint64_t *ntt, size_t batch,
+                                      cntt_inv_mode_t mode, cntt_mem_t where, void *stream) {
+    return product_op(pl, 1, standard, ntt, nullptr, batch, (int)mode, 0, where, (hipStream_t)stream);
+}
+extern "C" int cntt_product_mul_assign_normalize_batch(const cntt_product_t *pl, uint64_t *lhs, const uint64_t *rhs,
+                                                       size_t batch, cntt_mem_t where, void *stream) {
+    return product_op(pl, 2, lhs, const_cast<uint64_t *>(rhs), nullptr, batch, 0, 0, where, (hipStream_t)stream);
+}
+extern "C" int cntt_product_normalize_batch(const cntt_product_t *pl, uint64_t *values, size_t batch, cntt_mem_t where,
+                                            void *stream) {
+    return product_op(pl, 3, values, nullptr, nullptr, batch, 0, 0, where, (hipStream_t)stream);
+}
+extern "C" int cntt_product_mul_accumulate_batch(const cntt_product_t *pl, uint64_t *acc, const uint64_t *lhs,
+                                                 const uint64_t *rhs, size_t batch, cntt_mem_t where, void *stream) {
+    return product_op(pl, 4, acc, const_cast<uint64_t *>(lhs), rhs, batch, 0, 0, where, (hipStream_t)stream);
+}

@@ -1,7 +1,8 @@
 /*
  * cntt.h -- C ABI of libcntt_hip.so, the MI355X (gfx950) drop-in for the hot path of
  * zama-ai/concrete-ntt v0.2.0: Plan::try_new / fwd / inv / mul_assign_normalize / normalize /
- * mul_accumulate for prime32 / prime64, and the native* / native_binary* polynomial products.
+ * mul_accumulate for prime32 / prime64, the native* / native_binary* polynomial products, and
+ * product::Plan (the CRT-of-primes plan built on the prime plans).
  *
  * The reference has no FFI layer: its boundary is its public Rust API.  Each entry
  * point below replaces the Rust item cited next to it (paths relative to the reference tree); a Rust
@@ -176,6 +177,53 @@ int cntt_native_inv_batch(const cntt_native_t *plan, void *value, void *const *r
  * reserve it ahead of a timed or captured region with cntt_native_reserve(). */
 int cntt_native_negacyclic_polymul_batch(const cntt_native_t *plan, void *prod, const void *lhs, const void *rhs, size_t batch, cntt_mem_t where, void *stream);
 int cntt_native_reserve(const cntt_native_t *plan, size_t batch);
+
+/* ===================================================================================== */
+/* product::Plan  (src/product.rs:139-149): negacyclic NTT modulo a product of distinct    */
+/* primes that fits u64 -- the interface tfhe-rs calls.                                    */
+/*                                                                                       */
+/* NTT-domain buffer of ONE polynomial, in u64 words (src/product.rs:261-270): the u32     */
+/* residues of the primes below 2^32 (ascending, n u32 each, two per word), then the u64   */
+/* residues of the other primes (n words each); cntt_product_ntt_domain_len() words.       */
+/* _batch calls take `batch` polynomials: `standard` back to back (b at base + b*n), the   */
+/* NTT domain PLANE-MAJOR: for each prime in that same order, the residues of all `batch`  */
+/* polynomials back to back (plane of prime k holds batch*n residues).  batch == 1 is the  */
+/* reference layout.                                                                       */
+/* ===================================================================================== */
+typedef struct cntt_product cntt_product_t;
+typedef enum cntt_fwd_mode { CNTT_FWD_GENERIC = 0, CNTT_FWD_BOUNDED = 1 } cntt_fwd_mode_t;    /* FwdMode src/product.rs:124-129; Bounded(bound) */
+typedef enum cntt_inv_mode { CNTT_INV_REPLACE = 0, CNTT_INV_ACCUMULATE = 1 } cntt_inv_mode_t; /* InvMode src/product.rs:131-136 */
+
+/* Plan::try_new(polynomial_size, modulus, factors) src/product.rs:153-247.  CNTT_NONE when the reference returns
+ * None: odd size, a zero or repeated factor, product of the factors (1s skipped) != modulus or overflowing u64,
+ * or a factor for which prime32/prime64::Plan::try_new is None. */
+int cntt_product_plan_new(size_t polynomial_size, uint64_t modulus, const uint64_t *factors, size_t nfactors, cntt_product_t **out);
+cntt_product_t *cntt_product_plan_clone(const cntt_product_t *plan);   /* #[derive(Clone)] src/product.rs:138 */
+void cntt_product_plan_free(cntt_product_t *plan);
+size_t cntt_product_ntt_size(const cntt_product_t *plan);              /* src/product.rs:251-253 */
+uint64_t cntt_product_modulus(const cntt_product_t *plan);             /* src/product.rs:257-259 */
+size_t cntt_product_ntt_domain_len(const cntt_product_t *plan);        /* src/product.rs:268-270 */
+int cntt_product_nprimes32(const cntt_product_t *plan);                /* plan_32.len() */
+int cntt_product_nprimes64(const cntt_product_t *plan);                /* plan_64.len() */
+uint64_t cntt_product_prime(const cntt_product_t *plan, int i);        /* i-th factor after sorting and dropping 1s */
+const cntt_plan32_t *cntt_product_ntt32(const cntt_product_t *plan, int i); /* borrowed plan_32[i] */
+const cntt_plan64_t *cntt_product_ntt64(const cntt_product_t *plan, int i); /* borrowed plan_64[i] */
+/* private field modular_inverses (src/product.rs:207-229), len = k(k-1)/2, for parity tests */
+int cntt_product_modular_inverses(const cntt_product_t *plan, uint64_t *out, size_t len);
+
+/* Plan::fwd(ntt, standard, mode) src/product.rs:273-357; `bound` is read only for CNTT_FWD_BOUNDED */
+int cntt_product_fwd(const cntt_product_t *plan, uint64_t *ntt, size_t ntt_len, const uint64_t *standard, size_t standard_len, cntt_fwd_mode_t mode, uint64_t bound);
+/* Plan::inv(standard, ntt, mode) src/product.rs:360-879; like the reference it leaves the inverse-transformed residues in `ntt` */
+int cntt_product_inv(const cntt_product_t *plan, uint64_t *standard, size_t standard_len, uint64_t *ntt, size_t ntt_len, cntt_inv_mode_t mode);
+int cntt_product_mul_assign_normalize(const cntt_product_t *plan, uint64_t *lhs, size_t lhs_len, const uint64_t *rhs, size_t rhs_len); /* src/product.rs:885-913 */
+int cntt_product_normalize(const cntt_product_t *plan, uint64_t *values, size_t len);                                                  /* src/product.rs:917-931 */
+int cntt_product_mul_accumulate(const cntt_product_t *plan, uint64_t *acc, size_t acc_len, const uint64_t *lhs, size_t lhs_len, const uint64_t *rhs, size_t rhs_len); /* src/product.rs:935-966 */
+
+int cntt_product_fwd_batch(const cntt_product_t *plan, uint64_t *ntt, const uint64_t *standard, size_t batch, cntt_fwd_mode_t mode, uint64_t bound, cntt_mem_t where, void *stream);
+int cntt_product_inv_batch(const cntt_product_t *plan, uint64_t *standard, uint64_t *ntt, size_t batch, cntt_inv_mode_t mode, cntt_mem_t where, void *stream);
+int cntt_product_mul_assign_normalize_batch(const cntt_product_t *plan, uint64_t *lhs, const uint64_t *rhs, size_t batch, cntt_mem_t where, void *stream);
+int cntt_product_normalize_batch(const cntt_product_t *plan, uint64_t *values, size_t batch, cntt_mem_t where, void *stream);
+int cntt_product_mul_accumulate_batch(const cntt_product_t *plan, uint64_t *acc, const uint64_t *lhs, const uint64_t *rhs, size_t batch, cntt_mem_t where, void *stream);
 
 /* ===================================================================================== */
 /* utilities (not part of the reference API)                                              */

@@ -1420,6 +1420,240 @@ void orc_native_negacyclic_polymul(const orc_native *pl, void *prod, const void 
 }
 
 /* ========================================================================= */
+/* product::Plan  (src/product.rs)                                           */
+/* ========================================================================= */
+static uint32_t p_sub_mod_u32(uint32_t m, uint32_t a, uint32_t b) { return a >= b ? a - b : a - b + m; } /* :76-82 */
+static uint64_t p_sub_mod_u64(uint64_t m, uint64_t a, uint64_t b) { return a >= b ? a - b : a - b + m; } /* :67-73 */
+static uint64_t p_add_mod_u64(uint64_t m, uint64_t a, uint64_t b) { /* :85-92 */
+    uint64_t sum = a + b;
+    int overflow = sum < a;
+    return (sum >= m || overflow) ? sum - m : sum;
+}
+static uint32_t p_add_mod_u32(uint32_t m, uint32_t a, uint32_t b) { /* :107-114 */
+    uint32_t sum = a + b;
+    int overflow = sum < a;
+    return (sum >= m || overflow) ? sum - m : sum;
+}
+static uint32_t modular_inv_u32(uint32_t modulus, uint32_t n) { /* :22-42 extended Euclid */
+    uint32_t old_r = n % modulus, r = modulus, old_s = 1, s = 0;
+    while (r != 0) {
+        uint32_t q = old_r / r;
+        uint32_t nr = old_r - q * r;
+        old_r = r;
+        r = nr;
+        uint32_t ns = p_sub_mod_u32(modulus, old_s, mul_mod32(modulus, q, s));
+        old_s = s;
+        s = ns;
+    }
+    return old_s;
+}
+static uint64_t modular_inv_u64(uint64_t modulus, uint64_t n) { /* :44-64 */
+    uint64_t old_r = n % modulus, r = modulus, old_s = 1, s = 0;
+    while (r != 0) {
+        uint64_t q = old_r / r;
+        uint64_t nr = old_r - q * r;
+        old_r = r;
+        r = nr;
+        uint64_t ns = p_sub_mod_u64(modulus, old_s, orc_mul_mod64(modulus, q, s));
+        old_s = s;
+        s = ns;
+    }
+    return old_s;
+}
+static int cmp_u64(const void *a, const void *b) {
+    uint64_t x = *(const uint64_t *)a, y = *(const uint64_t *)b;
+    return x < y ? -1 : (x > y ? 1 : 0);
+}
+
+orc_product *orc_product_try_new(size_t n, uint64_t modulus, const uint64_t *factors, size_t nfactors) { /* :153-247 */
+    if (n % 2 != 0 || nfactors > 16) return NULL;
+    uint64_t primes[16];
+    memcpy(primes, factors, nfactors * sizeof(uint64_t));
+    qsort(primes, nfactors, sizeof(uint64_t), cmp_u64);
+    uint64_t prev = 0;
+    for (size_t i = 0; i < nfactors; ++i) { /* zeros / duplicates */
+        if (primes[i] == prev) return NULL;
+        prev = primes[i];
+    }
+    size_t start = 0;
+    while (start < nfactors && primes[start] == 1) ++start;
+    uint64_t prod = 1;
+    for (size_t i = start; i < nfactors; ++i) { /* checked_mul */
+        u128 w = (u128)prod * primes[i];
+        if (w >> 64) return NULL;
+        prod = (uint64_t)w;
+    }
+    if (prod != modulus) return NULL;
+    orc_product *pl = (orc_product *)calloc(1, sizeof(*pl));
+    pl->n = n;
+    pl->modulus = modulus;
+    size_t len = nfactors - start;
+    for (size_t i = 0; i < len; ++i) pl->primes[i] = primes[start + i];
+    for (size_t i = 0; i < len; ++i) {
+        if (pl->primes[i] < ((uint64_t)1 << 32)) {
+            orc_plan32 *sub = orc_plan32_try_new(n, (uint32_t)pl->primes[i], NULL);
+            if (!sub) {
+                orc_product_free(pl);
+                return NULL;
+            }
+            pl->p32[pl->n32++] = sub;
+        } else {
+            orc_plan64 *sub = orc_plan64_try_new(n, pl->primes[i], NULL);
+            if (!sub) {
+                orc_product_free(pl);
+                return NULL;
+            }
+            pl->p64[pl->n64++] = sub;
+        }
+    }
+    size_t off = 0;
+    for (size_t j = 0; j < len; ++j)
+        for (size_t i = 0; i < j; ++i)
+            pl->modular_inverses[off++] = (j < (size_t)pl->n32)
+                                              ? (uint64_t)modular_inv_u32((uint32_t)pl->primes[j], (uint32_t)pl->primes[i])
+                                              : modular_inv_u64(pl->primes[j], pl->primes[i]);
+    return pl;
+}
+void orc_product_free(orc_product *pl) {
+    if (!pl) return;
+    for (int i = 0; i < 16; ++i) {
+        orc_plan32_free(pl->p32[i]);
+        orc_plan64_free(pl->p64[i]);
+    }
+    free(pl);
+}
+size_t orc_product_modular_inverses(const orc_product *pl, uint64_t *out) {
+    size_t len = (size_t)(pl->n32 + pl->n64), cnt = len ? len * (len - 1) / 2 : 0;
+    memcpy(out, pl->modular_inverses, cnt * sizeof(uint64_t));
+    return cnt;
+}
+size_t orc_product_ntt_domain_len(const orc_product *pl) { return (pl->n / 2) * (size_t)pl->n32 + pl->n * (size_t)pl->n64; }
+
+void orc_product_fwd(const orc_product *pl, uint64_t *ntt, const uint64_t *standard, int bounded, uint64_t bound) {
+    size_t n = pl->n;
+    uint32_t *ntt32 = (uint32_t *)ntt;
+    uint64_t *ntt64 = ntt + (n / 2) * (size_t)pl->n32;
+    if (pl->n32 == 0 && pl->n64 == 1) { /* :282-286 */
+        memcpy(ntt64, standard, n * 8);
+        orc_plan64_fwd(pl->p64[0], ntt64);
+        return;
+    }
+    if (pl->n32 == 1 && pl->n64 == 0) { /* :287-293: truncation, no % */
+        for (size_t i = 0; i < n; ++i) ntt32[i] = (uint32_t)standard[i];
+        orc_plan32_fwd(pl->p32[0], ntt32);
+        return;
+    }
+    if (pl->n32 == 2 && pl->n64 == 0) { /* :295-335 */
+        uint32_t *ntt0 = ntt32, *ntt1 = ntt32 + n;
+        uint32_t p0 = pl->p32[0]->p, p1 = pl->p32[1]->p;
+        uint64_t p = pl->modulus;
+        uint32_t p_u32 = (uint32_t)p;
+        if (bounded && bound < (uint64_t)p0 && bound < (uint64_t)p1) {
+            for (size_t i = 0; i < n; ++i) {
+                int positive = standard[i] < p / 2;
+                uint32_t s = (uint32_t)standard[i];
+                uint32_t complement = p_u32 - s;
+                ntt0[i] = positive ? s : p0 - complement;
+                ntt1[i] = positive ? s : p1 - complement;
+            }
+        } else {
+            for (size_t i = 0; i < n; ++i) {
+                ntt0[i] = (uint32_t)(standard[i] % p0);
+                ntt1[i] = (uint32_t)(standard[i] % p1);
+            }
+        }
+        orc_plan32_fwd(pl->p32[0], ntt0);
+        orc_plan32_fwd(pl->p32[1], ntt1);
+        return;
+    }
+    for (int k = 0; k < pl->n32; ++k) { /* :337-345 */
+        uint32_t *dst = ntt32 + (size_t)k * n;
+        for (size_t i = 0; i < n; ++i) dst[i] = (uint32_t)(standard[i] % pl->p32[k]->p);
+        orc_plan32_fwd(pl->p32[k], dst);
+    }
+    for (int k = 0; k < pl->n64; ++k) { /* :347-355 */
+        uint64_t *dst = ntt64 + (size_t)k * n;
+        for (size_t i = 0; i < n; ++i) dst[i] = standard[i] % pl->p64[k]->p;
+        orc_plan64_fwd(pl->p64[k], dst);
+    }
+}
+
+void orc_product_inv(const orc_product *pl, uint64_t *standard, uint64_t *ntt, int accumulate) {
+    size_t n = pl->n;
+    uint32_t *ntt32 = (uint32_t *)ntt;
+    uint64_t *ntt64 = ntt + (n / 2) * (size_t)pl->n32;
+    for (int k = 0; k < pl->n32; ++k) orc_plan32_inv(pl->p32[k], ntt32 + (size_t)k * n);
+    for (int k = 0; k < pl->n64; ++k) orc_plan64_inv(pl->p64[k], ntt64 + (size_t)k * n);
+    uint64_t p = pl->modulus;
+    if (pl->n32 == 0 && pl->n64 == 0) { /* :378-384 */
+        if (!accumulate) memset(standard, 0, n * 8);
+        return;
+    }
+    if (pl->n32 == 0 && pl->n64 == 1) { /* :386-398 */
+        for (size_t i = 0; i < n; ++i) standard[i] = accumulate ? p_add_mod_u64(pl->p64[0]->p, standard[i], ntt64[i]) : ntt64[i];
+        return;
+    }
+    if (pl->n32 == 1 && pl->n64 == 0) { /* :399-415 */
+        for (size_t i = 0; i < n; ++i)
+            standard[i] = accumulate ? (uint64_t)p_add_mod_u32(pl->p32[0]->p, (uint32_t)standard[i], ntt32[i]) : (uint64_t)ntt32[i];
+        return;
+    }
+    /* general Garner (Knuth 4.3.2), src/product.rs:791-879; the u32x2 special case :419-789 computes the same
+     * digits v0 = u0, v1 = (u1 - v0) * p0^-1 mod p1 (Shoup or exact product: equal values) */
+    size_t len = (size_t)(pl->n32 + pl->n64);
+    for (size_t idx = 0; idx < n; ++idx) {
+        uint64_t v[16];
+        size_t off = 0;
+        for (size_t j = 0; j < len; ++j) {
+            uint64_t pj = pl->primes[j];
+            uint64_t x = (j < (size_t)pl->n32) ? (uint64_t)ntt32[j * n + idx] : ntt64[(j - (size_t)pl->n32) * n + idx];
+            for (size_t i = 0; i < j; ++i) {
+                uint64_t inv = pl->modular_inverses[off + i];
+                if (j < (size_t)pl->n32) {
+                    uint32_t diff = p_sub_mod_u32((uint32_t)pj, (uint32_t)x, (uint32_t)v[i]);
+                    x = mul_mod32((uint32_t)pj, diff, (uint32_t)inv);
+                } else {
+                    uint64_t diff = p_sub_mod_u64(pj, x, v[i]);
+                    x = orc_mul_mod64(pj, diff, inv);
+                }
+            }
+            off += j;
+            v[j] = x;
+        }
+        uint64_t acc = 0;
+        for (size_t j = len; j-- > 0;) { /* :861-872 */
+            acc *= pl->primes[j];
+            acc += v[j];
+        }
+        standard[idx] = accumulate ? p_add_mod_u64(p, standard[idx], acc) : acc;
+    }
+}
+
+void orc_product_mul_assign_normalize(const orc_product *pl, uint64_t *lhs, const uint64_t *rhs) {
+    size_t n = pl->n;
+    for (int k = 0; k < pl->n32; ++k)
+        orc_plan32_mul_assign_normalize(pl->p32[k], (uint32_t *)lhs + (size_t)k * n, (const uint32_t *)rhs + (size_t)k * n, n);
+    size_t o = (n / 2) * (size_t)pl->n32;
+    for (int k = 0; k < pl->n64; ++k)
+        orc_plan64_mul_assign_normalize(pl->p64[k], lhs + o + (size_t)k * n, rhs + o + (size_t)k * n, n);
+}
+void orc_product_normalize(const orc_product *pl, uint64_t *values) {
+    size_t n = pl->n;
+    for (int k = 0; k < pl->n32; ++k) orc_plan32_normalize(pl->p32[k], (uint32_t *)values + (size_t)k * n, n);
+    size_t o = (n / 2) * (size_t)pl->n32;
+    for (int k = 0; k < pl->n64; ++k) orc_plan64_normalize(pl->p64[k], values + o + (size_t)k * n, n);
+}
+void orc_product_mul_accumulate(const orc_product *pl, uint64_t *acc, const uint64_t *lhs, const uint64_t *rhs) {
+    size_t n = pl->n;
+    for (int k = 0; k < pl->n32; ++k)
+        orc_plan32_mul_accumulate(pl->p32[k], (uint32_t *)acc + (size_t)k * n, (const uint32_t *)lhs + (size_t)k * n,
+                                  (const uint32_t *)rhs + (size_t)k * n, n);
+    size_t o = (n / 2) * (size_t)pl->n32;
+    for (int k = 0; k < pl->n64; ++k)
+        orc_plan64_mul_accumulate(pl->p64[k], acc + o + (size_t)k * n, lhs + o + (size_t)k * n, rhs + o + (size_t)k * n, n);
+}
+
+/* ========================================================================= */
 /* schoolbook negacyclic convolution: src/prime64.rs:1143-1182               */
 /* ========================================================================= */
 static inline uint64_t t_add64(uint64_t p, uint64_t a, uint64_t b) {

@@ -137,6 +137,32 @@ void orc_native_inv(const orc_native *plan, void *value, void *const *residues);
 /* src/native64.rs:1042-1069 */
 void orc_native_negacyclic_polymul(const orc_native *plan, void *prod, const void *lhs, const void *rhs);
 
+/* ---- product::Plan (src/product.rs:139-967): NTT modulo a product of distinct primes ----
+ * NTT-domain layout of ONE polynomial (src/product.rs:261-270): n32 * n u32 residues (packed two per
+ * u64 word), then n64 * n u64 residues; ntt_domain_len = (n/2)*n32 + n*n64 words. */
+typedef struct orc_product {
+    size_t n;
+    uint64_t modulus;
+    int n32, n64;               /* primes below / not below 2^32, ascending (src/product.rs:183-184) */
+    uint64_t primes[16];
+    orc_plan32 *p32[16];
+    orc_plan64 *p64[16];
+    uint64_t modular_inverses[120]; /* src/product.rs:207-229: for j, for i < j: p_i^-1 mod p_j */
+} orc_product;
+/* FwdMode: bounded < 0 -> Generic, else Bounded(bound) */
+orc_product *orc_product_try_new(size_t n, uint64_t modulus, const uint64_t *factors, size_t nfactors); /* :153-247 */
+void orc_product_free(orc_product *plan);
+size_t orc_product_modular_inverses(const orc_product *plan, uint64_t *out); /* copies the field, returns its length */
+size_t orc_product_ntt_domain_len(const orc_product *plan);                                            /* :261-270 */
+void orc_product_fwd(const orc_product *plan, uint64_t *ntt, const uint64_t *standard, int bounded,
+                     uint64_t bound);                                                                  /* :273-357 */
+/* accumulate == 0 -> InvMode::Replace, else InvMode::Accumulate */
+void orc_product_inv(const orc_product *plan, uint64_t *standard, uint64_t *ntt, int accumulate);      /* :360-879 */
+void orc_product_mul_assign_normalize(const orc_product *plan, uint64_t *lhs, const uint64_t *rhs);    /* :885-913 */
+void orc_product_normalize(const orc_product *plan, uint64_t *values);                                 /* :917-931 */
+void orc_product_mul_accumulate(const orc_product *plan, uint64_t *acc, const uint64_t *lhs,
+                                const uint64_t *rhs);                                                  /* :935-966 */
+
 /* ---- the reference tests' own oracle: schoolbook negacyclic convolution ----
  * src/prime64.rs:1170-1182 (p == 0 means wrapping arithmetic mod 2^64) */
 void orc_negacyclic_convolution64(size_t n, uint64_t p, const uint64_t *lhs, const uint64_t *rhs,

@@ -83,6 +83,15 @@ def lib(native=False):
         "orc_native_fwd_binary": (None, [c_vp, c_vp, c_vp]),
         "orc_native_inv": (None, [c_vp, c_vp, c_vp]),
         "orc_native_negacyclic_polymul": (None, [c_vp, c_vp, c_vp, c_vp]),
+        "orc_product_try_new": (c_vp, [c_sz, c_u64, c_vp, c_sz]),
+        "orc_product_free": (None, [c_vp]),
+        "orc_product_ntt_domain_len": (c_sz, [c_vp]),
+        "orc_product_modular_inverses": (c_sz, [c_vp, c_vp]),
+        "orc_product_fwd": (None, [c_vp, c_vp, c_vp, c_int, c_u64]),
+        "orc_product_inv": (None, [c_vp, c_vp, c_vp, c_int]),
+        "orc_product_mul_assign_normalize": (None, [c_vp, c_vp, c_vp]),
+        "orc_product_normalize": (None, [c_vp, c_vp]),
+        "orc_product_mul_accumulate": (None, [c_vp, c_vp, c_vp, c_vp]),
         "orc_negacyclic_convolution64": (None, [c_sz, c_u64, c_vp, c_vp, c_vp]),
         "orc_negacyclic_convolution32": (None, [c_sz, c_u32, c_vp, c_vp, c_vp]),
         "orc_negacyclic_convolution128": (None, [c_sz, c_vp, c_vp, c_vp]),
@@ -243,6 +252,58 @@ class Native:
             self._L.orc_native_free(self._h)
         except Exception:
             pass
+
+
+class Product:
+    """product::Plan (src/product.rs:139-967). fwd mode: bound=None -> FwdMode::Generic, else
+    FwdMode::Bounded(bound); inv mode: accumulate=False -> InvMode::Replace."""
+
+    def __init__(self, handle, n):
+        self._L = lib()
+        self._h = handle
+        self.n = n
+
+    @classmethod
+    def try_new(cls, n, modulus, factors):
+        f = np.ascontiguousarray(np.array(list(factors), dtype=np.uint64))
+        h = lib().orc_product_try_new(n, modulus, _ptr(f), f.size)
+        return cls(h, n) if h else None
+
+    def ntt_domain_len(self):
+        return self._L.orc_product_ntt_domain_len(self._h)
+
+    def modular_inverses(self):
+        out = np.zeros(120, dtype=np.uint64)
+        return out[: self._L.orc_product_modular_inverses(self._h, _ptr(out))].copy()
+
+    def fwd(self, ntt, standard, bound=None):
+        assert ntt.dtype == np.uint64 and ntt.size == self.ntt_domain_len() and standard.size == self.n
+        self._L.orc_product_fwd(self._h, _ptr(ntt), _ptr(standard), 0 if bound is None else 1, 0 if bound is None else bound)
+
+    def inv(self, standard, ntt, accumulate=False):
+        assert ntt.size == self.ntt_domain_len() and standard.size == self.n
+        self._L.orc_product_inv(self._h, _ptr(standard), _ptr(ntt), 1 if accumulate else 0)
+
+    def mul_assign_normalize(self, lhs, rhs):
+        self._L.orc_product_mul_assign_normalize(self._h, _ptr(lhs), _ptr(rhs))
+
+    def normalize(self, values):
+        self._L.orc_product_normalize(self._h, _ptr(values))
+
+    def mul_accumulate(self, acc, lhs, rhs):
+        self._L.orc_product_mul_accumulate(self._h, _ptr(acc), _ptr(lhs), _ptr(rhs))
+
+    def __del__(self):
+        try:
+            self._L.orc_product_free(self._h)
+        except Exception:
+            pass
+
+
+def largest_prime_in_arithmetic_progression64(factor, offset, lo, hi):
+    out = ctypes.c_uint64(0)
+    ok = lib().orc_largest_prime_in_arithmetic_progression64(factor, offset, lo, hi, ctypes.byref(out))
+    return out.value if ok else None
 
 
 def fill_uniform(count, bound, seed, bits):
