@@ -12,6 +12,7 @@ pub mod ffi {
     #[repr(C)] pub struct cntt_plan64 { _p: [u8; 0] }
     #[repr(C)] pub struct cntt_plan32 { _p: [u8; 0] }
     #[repr(C)] pub struct cntt_native { _p: [u8; 0] }
+    #[repr(C)] pub struct cntt_product { _p: [u8; 0] }
     pub const CNTT_OK: c_int = 0;
     pub const CNTT_NONE: c_int = 1;
     pub const CNTT_EINVAL: c_int = 2;
@@ -53,6 +54,17 @@ pub mod ffi {
         pub fn cntt_native_fwd_binary(p: *const cntt_native, value: *const c_void, len: usize, residues: *const *mut c_void) -> c_int;
         pub fn cntt_native_inv(p: *const cntt_native, value: *mut c_void, len: usize, residues: *const *mut c_void) -> c_int;
         pub fn cntt_native_negacyclic_polymul(p: *const cntt_native, prod: *mut c_void, pl: usize, lhs: *const c_void, ll: usize, rhs: *const c_void, rl: usize) -> c_int;
+        pub fn cntt_product_plan_new(n: usize, modulus: u64, factors: *const u64, nfactors: usize, out: *mut *mut cntt_product) -> c_int;
+        pub fn cntt_product_plan_clone(p: *const cntt_product) -> *mut cntt_product;
+        pub fn cntt_product_plan_free(p: *mut cntt_product);
+        pub fn cntt_product_ntt_size(p: *const cntt_product) -> usize;
+        pub fn cntt_product_modulus(p: *const cntt_product) -> u64;
+        pub fn cntt_product_ntt_domain_len(p: *const cntt_product) -> usize;
+        pub fn cntt_product_fwd(p: *const cntt_product, ntt: *mut u64, nl: usize, standard: *const u64, sl: usize, mode: c_int, bound: u64) -> c_int;
+        pub fn cntt_product_inv(p: *const cntt_product, standard: *mut u64, sl: usize, ntt: *mut u64, nl: usize, mode: c_int) -> c_int;
+        pub fn cntt_product_mul_assign_normalize(p: *const cntt_product, lhs: *mut u64, ll: usize, rhs: *const u64, rl: usize) -> c_int;
+        pub fn cntt_product_normalize(p: *const cntt_product, v: *mut u64, len: usize) -> c_int;
+        pub fn cntt_product_mul_accumulate(p: *const cntt_product, acc: *mut u64, al: usize, lhs: *const u64, ll: usize, rhs: *const u64, rl: usize) -> c_int;
         pub fn cntt_native_negacyclic_polymul_batch(p: *const cntt_native, prod: *mut c_void, lhs: *const c_void, rhs: *const c_void, batch: usize, mem: c_int, stream: *mut c_void) -> c_int;
     }
 }
@@ -177,4 +189,54 @@ pub mod native64 {
         }
     }
     impl Drop for Plan32 { fn drop(&mut self) { unsafe { ffi::cntt_native_plan_free(self.0) } } }
+}
+
+/// product::Plan (src/product.rs:139-967).
+pub mod product {
+    use super::*;
+    #[derive(Copy, Clone, Debug)]
+    pub enum FwdMode { Generic, Bounded(u64) }
+    #[derive(Copy, Clone, Debug)]
+    pub enum InvMode { Replace, Accumulate }
+    pub struct Plan(*mut ffi::cntt_product);
+    unsafe impl Send for Plan {}
+    unsafe impl Sync for Plan {}
+    impl Plan {
+        pub fn try_new(polynomial_size: usize, modulus: u64, factors: impl IntoIterator<Item = u64>) -> Option<Self> {
+            let f: Vec<u64> = factors.into_iter().collect();
+            let mut out = core::ptr::null_mut();
+            match unsafe { ffi::cntt_product_plan_new(polynomial_size, modulus, f.as_ptr(), f.len(), &mut out) } {
+                ffi::CNTT_OK => Some(Self(out)),
+                ffi::CNTT_NONE => None,
+                rc => { check(rc); None }
+            }
+        }
+        pub fn ntt_size(&self) -> usize { unsafe { ffi::cntt_product_ntt_size(self.0) } }
+        pub fn modulus(&self) -> u64 { unsafe { ffi::cntt_product_modulus(self.0) } }
+        pub fn ntt_domain_len(&self) -> usize { unsafe { ffi::cntt_product_ntt_domain_len(self.0) } }
+        #[track_caller]
+        pub fn fwd(&self, ntt: &mut [u64], standard: &[u64], mode: FwdMode) {
+            let (m, b) = match mode { FwdMode::Generic => (0, 0), FwdMode::Bounded(b) => (1, b) };
+            check(unsafe { ffi::cntt_product_fwd(self.0, ntt.as_mut_ptr(), ntt.len(), standard.as_ptr(), standard.len(), m, b) })
+        }
+        #[track_caller]
+        pub fn inv(&self, standard: &mut [u64], ntt: &mut [u64], mode: InvMode) {
+            let m = match mode { InvMode::Replace => 0, InvMode::Accumulate => 1 };
+            check(unsafe { ffi::cntt_product_inv(self.0, standard.as_mut_ptr(), standard.len(), ntt.as_mut_ptr(), ntt.len(), m) })
+        }
+        #[track_caller]
+        pub fn mul_assign_normalize(&self, lhs: &mut [u64], rhs: &[u64]) {
+            check(unsafe { ffi::cntt_product_mul_assign_normalize(self.0, lhs.as_mut_ptr(), lhs.len(), rhs.as_ptr(), rhs.len()) })
+        }
+        #[track_caller]
+        pub fn normalize(&self, values: &mut [u64]) {
+            check(unsafe { ffi::cntt_product_normalize(self.0, values.as_mut_ptr(), values.len()) })
+        }
+        #[track_caller]
+        pub fn mul_accumulate(&self, acc: &mut [u64], lhs: &[u64], rhs: &[u64]) {
+            check(unsafe { ffi::cntt_product_mul_accumulate(self.0, acc.as_mut_ptr(), acc.len(), lhs.as_ptr(), lhs.len(), rhs.as_ptr(), rhs.len()) })
+        }
+    }
+    impl Clone for Plan { fn clone(&self) -> Self { Self(unsafe { ffi::cntt_product_plan_clone(self.0) }) } }
+    impl Drop for Plan { fn drop(&mut self) { unsafe { ffi::cntt_product_plan_free(self.0) } } }
 }

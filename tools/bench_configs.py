@@ -72,8 +72,34 @@ def native_case(cls, n, batch, tag, binary):
     emit("%s negacyclic_polymul N=%d batch=%d" % (tag, n, batch), ms, batch, "polymul/s", 3 * n * 8 * batch)
 
 
+def product_case(n, primes, batch, tag):
+    from concrete_ntt_amd import product
+    big = 1
+    for q in primes:
+        big *= q
+    plan = product.Plan.try_new(n, big, primes)
+    std = torch.empty(batch * n, dtype=torch.int64, device="cuda")
+    cntt.fill_uniform(std, big, 77)
+    ntt = torch.zeros(batch * plan.ntt_domain_len(), dtype=torch.int64, device="cuda")
+    rhs = torch.zeros_like(ntt)
+    plan.fwd_batch(rhs, std)
+    # algorithmic bytes (one pass): standard words + NTT-domain words
+    by = (n + plan.ntt_domain_len()) * 8 * batch
+    emit("%s fwd N=%d batch=%d" % (tag, n, batch), timed(lambda: plan.fwd_batch(ntt, std), 10), batch, "poly/s", by)
+    emit("%s mul_assign_normalize N=%d batch=%d" % (tag, n, batch),
+         timed(lambda: plan.mul_assign_normalize_batch(ntt, rhs), 10), batch, "poly/s", 3 * plan.ntt_domain_len() * 8 * batch)
+    emit("%s inv(Replace) N=%d batch=%d" % (tag, n, batch),
+         timed(lambda: plan.inv_batch(std, ntt, product.InvMode.Replace), 10), batch, "poly/s", by)
+    emit("%s inv(Accumulate) N=%d batch=%d" % (tag, n, batch),
+         timed(lambda: plan.inv_batch(std, ntt, product.InvMode.Accumulate), 10), batch, "poly/s", by + n * 8 * batch)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["p64", "p32", "c4", "c3", "c5"]
+    which = sys.argv[1:] or ["p64", "p32", "c4", "c3", "c5", "prod"]
+    if "prod" in which:
+        product_case(2048, [4294955009, 4294914049], 32768, "product u32x2")
+        product_case(2048, [18446744069414584321], 32768, "product u64x1 (Solinas)")
+        product_case(1024, [61441, 59393, 40961, 18433], 65536, "product u32x4")
     if "p64" in which:
         prime_case(prime64, 64, 1024, P62, 65536, "prime64 (C2)")
     if "p32" in which:
