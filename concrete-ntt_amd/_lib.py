@@ -76,6 +76,7 @@ def lib():
             "normalize_batch": (c_int, [c_vp, c_vp, c_sz, c_int, c_vp]),
             "mul_accumulate_batch": (c_int, [c_vp, c_vp, c_vp, c_vp, c_sz, c_int, c_vp]),
             "mul_ntt_batch": (c_int, [c_vp, c_vp, c_vp, c_sz, c_int, c_vp]),
+            "external_product_batch": (c_int, [c_vp, c_vp, c_vp, c_vp, c_sz, c_sz, c_sz, c_int, c_int, c_vp]),
             "time_batch": (c_int, [c_vp, c_int, c_vp, c_vp, c_sz, c_int, c_vp, c_vp]),
         }
         for name, (res, args) in sig.items():

@@ -131,6 +131,17 @@ class PrimePlan:
             raise Panic("lhs and rhs_ntt must have the same shape and live in the same memory")
         check(getattr(lib(), self._p + "mul_ntt_batch")(self._h, lp, rp, batch, where, stream))
 
+    def external_product_batch(self, out, terms, key_ntt, nterms, nout, accumulate=False):
+        """Fused mul_accumulate chain: out[b][o] (+)= inv(sum_j fwd(terms[b][j]) . key_ntt[j][o]) -- the values of
+        fwd / mul_accumulate / inv (src/prime64.rs:794, :1085-1128, :872) called in sequence, in one pass over HBM."""
+        op, ob, where, stream = self._batch(out)
+        tp, tb, tw, _ = self._batch(terms)
+        kp, kb, kw, _ = self._batch(key_ntt)
+        if nout <= 0 or ob % nout or kb != nterms * nout or tb != (ob // nout) * nterms or tw != where or kw != where:
+            raise Panic("out: batch*nout, terms: batch*nterms, key_ntt: nterms*nout polynomials in the same memory")
+        check(getattr(lib(), self._p + "external_product_batch")(self._h, op, tp, kp, nterms, nout, ob // nout,
+                                                                 1 if accumulate else 0, where, stream))
+
     def normalize_batch(self, values):
         vp, batch, where, stream = self._batch(values)
         check(getattr(lib(), self._p + "normalize_batch")(self._h, vp, batch, where, stream))

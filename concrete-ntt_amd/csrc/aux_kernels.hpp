@@ -11,12 +11,12 @@ namespace cntt {
 // K3/K4: pointwise kernels.  src/prime64.rs:534-584,690-699 ; src/prime32.rs:383-408,477-488,575-598
 // (values equal the reference's Barrett-then-Shoup results: canonical a*b*N^-1, a*N^-1, acc+a*b)
 // ---------------------------------------------------------------------------------------------
-enum : int { PW_MUL_NORMALIZE = 0, PW_NORMALIZE = 1, PW_MUL_ACCUMULATE = 2 };
+enum : int { PW_MUL_NORMALIZE = 0, PW_NORMALIZE = 1, PW_MUL_ACCUMULATE = 2, PW_ADD = 3 };
 
 template <class T, int OP>
 __global__ __launch_bounds__(256) void pointwise_kernel(T *__restrict__ a, const T *__restrict__ b,
                                                         const T *__restrict__ c, const ModParams<T> P, size_t count) {
-    // OP == MUL_NORMALIZE: a <- a*b*ninv ; NORMALIZE: a <- a*ninv ; MUL_ACCUMULATE: a <- a + b*c
+    // OP == MUL_NORMALIZE: a <- a*b*ninv ; NORMALIZE: a <- a*ninv ; MUL_ACCUMULATE: a <- a + b*c ; ADD: a <- a + b
     constexpr int NV = 16 / sizeof(T);
     using V = __attribute__((ext_vector_type(NV))) T;
     const bool generic = P.cls == CLS_GENERIC;
@@ -32,6 +32,7 @@ __global__ __launch_bounds__(256) void pointwise_kernel(T *__restrict__ a, const
             if constexpr (OP == PW_MUL_NORMALIZE) va[k] = mul_normalize<T>(va[k], vb[k], P, generic);
             if constexpr (OP == PW_NORMALIZE) va[k] = normalize1<T>(va[k], P, generic);
             if constexpr (OP == PW_MUL_ACCUMULATE) va[k] = mul_acc<T>(va[k], vb[k], vc[k], P, generic);
+            if constexpr (OP == PW_ADD) va[k] = add_mod<T>(va[k], vb[k], P.p);
         }
         reinterpret_cast<V *>(a)[i] = va;
     }
@@ -40,6 +41,39 @@ __global__ __launch_bounds__(256) void pointwise_kernel(T *__restrict__ a, const
         if constexpr (OP == PW_MUL_NORMALIZE) a[i] = mul_normalize<T>(a[i], b[i], P, generic);
         if constexpr (OP == PW_NORMALIZE) a[i] = normalize1<T>(a[i], P, generic);
         if constexpr (OP == PW_MUL_ACCUMULATE) a[i] = mul_acc<T>(a[i], b[i], c[i], P, generic);
+        if constexpr (OP == PW_ADD) a[i] = add_mod<T>(a[i], b[i], P.p);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// mul_accumulate chain in the NTT domain, any transform size (the composed path behind
+// cntt_prime*_external_product_batch when the fused ExtWp kernel does not cover the size):
+//     acc[b][o][e] = sum_j t[b][j][e] * key[j][o][e] mod p        (src/prime64.rs:1085-1128 applied J times)
+// one thread per 16-byte vector of one (b, o) output polynomial; key is shared by the batch (L2).
+// ---------------------------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void ext_accumulate_kernel(T *__restrict__ acc, const T *__restrict__ t,
+                                                             const T *__restrict__ key, const ModParams<T> P,
+                                                             uint32_t logn, uint32_t nterms, uint32_t nout, size_t batch) {
+    constexpr int NV = 16 / sizeof(T);
+    using V = __attribute__((ext_vector_type(NV))) T;
+    const bool generic = P.cls == CLS_GENERIC;
+    const uint32_t lv = logn - (NV == 2 ? 1 : 2);  // log2 vectors per polynomial (n >= 16)
+    const size_t total = (batch * nout) << lv;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const size_t v = i & (((size_t)1 << lv) - 1), bo = i >> lv;
+        const size_t b = bo / nout, o = bo - b * nout;
+        V a;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) a[k] = 0;
+        for (uint32_t j = 0; j < nterms; ++j) {
+            const V x = reinterpret_cast<const V *>(t)[((b * nterms + j) << lv) + v];
+            const V y = reinterpret_cast<const V *>(key)[(((size_t)j * nout + o) << lv) + v];
+#pragma unroll
+            for (int k = 0; k < NV; ++k) a[k] = mul_acc<T>(a[k], x[k], y[k], P, generic);
+        }
+        reinterpret_cast<V *>(acc)[i] = a;
     }
 }
 

@@ -300,6 +300,72 @@ template <class T> static int mul_ntt_device(const PrimePlan<T> *pl, T *lhs, con
     return ntt_device<T>(pl, lhs, batch, true, st);
 }
 
+// mul_accumulate chain: out[b][o] (+)= inv(sum_j fwd(terms[b][j]) . key_ntt[j][o])  (device pointers).
+// Fused kernel when the transform lives in one wavefront group and nout <= 4; otherwise composed from the batched
+// kernels through a stream-ordered scratch allocation.
+template <class T>
+static int external_product_device(const PrimePlan<T> *pl, T *out, const T *terms, const T *key, size_t nterms,
+                                   size_t nout, size_t batch, bool accumulate, hipStream_t st) {
+    if (batch == 0 || nout == 0) return CNTT_OK;
+    if (batch * std::max(nterms, nout) >= ((size_t)1 << 32)) return fail(CNTT_EINVAL, "batch too large for one launch");
+    const size_t n = pl->n;
+    if (nterms == 0) {  // empty sum
+        if (!accumulate) HIP_TRY(hipMemsetAsync(out, 0, batch * nout * n * sizeof(T), st));
+        return CNTT_OK;
+    }
+    DeviceTables<T> t;
+    if (int rc = device_tables(pl, &t)) return rc;
+    const hipError_t e = launch_ext_ntt<T>(pl->logn, (int)pl->mp.cls, out, terms, key, t.fwd, t.inv, pl->mp, (uint32_t)batch,
+                                           (uint32_t)nterms, (uint32_t)nout, accumulate, st);
+    if (e == hipSuccess) return CNTT_OK;
+    if (e != hipErrorNotSupported) return fail(CNTT_EDEVICE, "fused mul_accumulate chain launch failed: %s", hipGetErrorString(e));
+    (void)hipGetLastError();
+    const size_t tw = batch * nterms * n, ow = batch * nout * n;
+    T *scratch = nullptr;
+    HIP_TRY(hipMallocAsync((void **)&scratch, (tw + (accumulate ? ow : 0)) * sizeof(T), st));
+    T *tn = scratch, *acc = accumulate ? scratch + tw : out;
+    int rc = CNTT_OK;
+    do {
+        if (hipMemcpyAsync(tn, terms, tw * sizeof(T), hipMemcpyDeviceToDevice, st) != hipSuccess) {
+            rc = fail(CNTT_EDEVICE, "device copy failed");
+            break;
+        }
+        if ((rc = ntt_device<T>(pl, tn, batch * nterms, false, st))) break;
+        hipLaunchKernelGGL((ext_accumulate_kernel<T>), dim3(ew_grid(ow / (16 / sizeof(T)))), dim3(256), 0, st, acc, tn, key,
+                           pl->mp, (uint32_t)pl->logn, (uint32_t)nterms, (uint32_t)nout, batch);
+        if (hipGetLastError() != hipSuccess) {
+            rc = fail(CNTT_EDEVICE, "ext_accumulate_kernel launch failed");
+            break;
+        }
+        if ((rc = ntt_device<T>(pl, acc, batch * nout, true, st))) break;
+        if (accumulate) rc = pointwise_device<T, PW_ADD>(pl, out, acc, nullptr, ow, st);
+    } while (false);
+    (void)hipFreeAsync(scratch, st);
+    return rc;
+}
+
+template <class T>
+static int external_product(const PrimePlan<T> *pl, T *out, const T *terms, const T *key, size_t nterms, size_t nout,
+                            size_t batch, int accumulate, cntt_mem_t where, hipStream_t st) {
+    if (!pl) return fail(CNTT_EINVAL, "plan is NULL");
+    if (batch == 0 || nout == 0) return CNTT_OK;
+    if (!out || (nterms && (!terms || !key))) return fail(CNTT_EINVAL, "NULL buffer");
+    if (where == CNTT_MEM_DEVICE) return external_product_device<T>(pl, out, terms, key, nterms, nout, batch, accumulate != 0, st);
+    const size_t n = pl->n, ob = batch * nout * n * sizeof(T), tb = batch * nterms * n * sizeof(T), kb = nterms * nout * n * sizeof(T);
+    DevBuf dout, dt, dk;
+    if (int rc = dout.alloc(ob)) return rc;
+    if (int rc = dt.alloc(tb)) return rc;
+    if (int rc = dk.alloc(kb)) return rc;
+    if (accumulate) HIP_TRY(hipMemcpyAsync(dout.p, out, ob, hipMemcpyHostToDevice, st));
+    if (tb) HIP_TRY(hipMemcpyAsync(dt.p, terms, tb, hipMemcpyHostToDevice, st));
+    if (kb) HIP_TRY(hipMemcpyAsync(dk.p, key, kb, hipMemcpyHostToDevice, st));
+    if (int rc = external_product_device<T>(pl, (T *)dout.p, (const T *)dt.p, (const T *)dk.p, nterms, nout, batch, accumulate != 0, st))
+        return rc;
+    HIP_TRY(hipMemcpyAsync(out, dout.p, ob, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return CNTT_OK;
+}
+
 // op: 0 fwd, 1 inv, 2 mul_assign_normalize, 3 normalize, 4 mul_accumulate, 5 mul_ntt ; count = total elements
 template <class T>
 static int prime_op(const PrimePlan<T> *pl, int op, T *a, const T *b, const T *c, size_t count, size_t batch,
@@ -447,6 +513,11 @@ static int time_batch(const PrimePlan<T> *pl, int op, T *bufs, const T *rhs, siz
                                                     void *st) {                                                     \
         return pl ? prime_op<T>(pl, 5, l, r, nullptr, batch * pl->n, batch, w, (hipStream_t)st)                     \
                   : fail(CNTT_EINVAL, "plan is NULL");                                                              \
+    }                                                                                                               \
+    extern "C" int cntt_prime##BITS##_external_product_batch(const PLAN *pl, T *out, const T *terms, const T *key_ntt,  \
+                                                            size_t nterms, size_t nout, size_t batch, int accumulate,  \
+                                                            cntt_mem_t where, void *stream) {                          \
+        return external_product<T>(pl, out, terms, key_ntt, nterms, nout, batch, accumulate, where, (hipStream_t)stream); \
     }                                                                                                               \
     extern "C" int cntt_prime##BITS##_time_batch(const PLAN *pl, int op, T *bufs, const T *rhs, size_t batch,       \
                                                  int reps, void *st, float *ms) {                                   \

@@ -169,7 +169,9 @@ struct NttKernel {
     // hipcc keeps ONE in-order vmcnt model per loop and waits for freshly issued loads at the loop header,
     // so a prefetch written in plain C++ is waited for at once.  These loads are issued from inline asm
     // (invisible to the compiler's counters); wait_async() is the single hand-placed counted wait.  The
-    // destination vectors must not be read between the two (they are only passed to wait_async).
+    // destination vectors must not be read between the two (they are only passed to wait_async), and a kernel
+    // that uses them must not spill: a destination register spilled or reassigned while the load is in flight
+    // is overwritten when the data lands (tests/test_host_plan.py checks the code objects for zero spills).
     static constexpr int ASYNC_NV = MAXV;  // elements per 16-byte load
     using AsyncVec = __attribute__((ext_vector_type(4))) uint32_t;
     template <uint32_t RM> static constexpr bool async_ok() { return vec_elems<RM>() == MAXV; }
@@ -589,6 +591,136 @@ __global__ __launch_bounds__(WPB, WPW) void mul_kernel_wp(T *__restrict__ lhs, c
     __shared__ __attribute__((aligned(16))) TwPair<T> imgf[K::FB::IMG_ENTRIES];
     __shared__ __attribute__((aligned(16))) TwPair<T> imgi[K::IB::IMG_ENTRIES];
     K::run(lhs, rhs_ntt, twf, twi, P, nsub, lds, imgf, imgi);
+}
+
+// -------------------------------------------------------------------------------------------------
+// Fused mul_accumulate chain (the step around the NTT in the reference's caller):
+//     for each o < NOUT:  out[b][o] (+)= inv( sum_{j < J} fwd(terms[b][j]) (.) key_ntt[j][o] )
+// i.e. what a caller of the reference writes as
+//     for j { plan.fwd(t_j); for o { plan.mul_accumulate(acc_o, t_j, key[j][o]) } }  for o { plan.inv(acc_o) }
+// (src/prime64.rs:794, :1085-1128, :872) with every intermediate kept in registers: (J + NOUT) * N words of HBM
+// traffic per batch element instead of (2J + 3*J*NOUT + 2*NOUT) * N.  `key_ntt` (J * NOUT polynomials, shared
+// by the whole batch) is read in the forward transform's last register layout and stays L2-resident.
+// -------------------------------------------------------------------------------------------------
+template <int V> struct IntC { static constexpr int value = V; };
+template <int I, int N, class F> __device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) {
+        f(IntC<I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+template <class T, int LOGN, int CLS, int WPB, int NOUT>
+struct ExtWp {
+    using F = NttWp<T, LOGN, false, CLS, WPB>;
+    using I = NttWp<T, LOGN, true, CLS, WPB>;
+    using FB = typename F::B;
+    using IB = typename I::B;
+    static constexpr int E = FB::E, TPP = FB::TPP, NPASS = FB::NPASS, PPB = WPB / TPP;
+    static constexpr uint32_t FULL = FB::FULL;
+    static constexpr uint32_t RM0 = FB::S::RMASK[0], RMM = FB::S::RMASK[NPASS - 1], RML = IB::S::RMASK[NPASS - 1];
+    static_assert(RMM == IB::S::RMASK[0], "forward and inverse schedules must mirror each other");
+    static constexpr uint32_t IO_RM = F::IO_RM;
+
+    // acc[e] <- acc[e] + r[e] * key[e] with the key polynomial read from global memory in layout RMM, one
+    // 16-byte vector at a time (no E-element staging array: the accumulators already fill the register file)
+    static __device__ __forceinline__ void mul_acc_key(T (&acc)[E], const T (&r)[E], const T *__restrict__ key,
+                                                       uint32_t ebase, const ModParams<T> &P) {
+        constexpr int NV = FB::template vec_elems<RMM>();
+        using V = typename VecOf<T, NV>::type;
+        const bool generic = CLS == CLS_GENERIC;
+#pragma unroll
+        for (int j = 0; j < E; j += NV) {
+            const uint32_t e = ebase | cdep((uint32_t)j, RMM);
+            if constexpr (NV == 1) {
+                acc[j] = mul_acc<T>(acc[j], r[j], key[e], P, generic);
+            } else {
+                const V v = *reinterpret_cast<const V *>(&key[e]);
+#pragma unroll
+                for (int i = 0; i < NV; ++i) acc[j + i] = mul_acc<T>(acc[j + i], r[j + i], v[i], P, generic);
+            }
+        }
+    }
+
+    // The next term is prefetched with ordinary loads (not NttKernel::gather_async): this kernel's register
+    // footprint can make hipcc spill, and an asynchronous inline-asm load into a register that the compiler
+    // spills or reassigns before the data lands corrupts whatever lives there by then.
+    static __device__ __forceinline__ void run(T *__restrict__ out, const T *__restrict__ terms,
+                                               const T *__restrict__ key_ntt, const TwPair<T> *__restrict__ twf,
+                                               const TwPair<T> *__restrict__ twi, const ModParams<T> &P, uint32_t nb,
+                                               uint32_t nterms, bool accumulate, T *lds_all, TwPair<T> *imgf,
+                                               TwPair<T> *imgi) {
+        FB::fill_image(imgf, twf);
+        IB::fill_image(imgi, twi);
+        __syncthreads();
+        const uint32_t tid = threadIdx.x & (TPP - 1);
+        const uint32_t pl = threadIdx.x / TPP;
+        T *lds = lds_all + ((size_t)pl << LOGN);
+        constexpr uint32_t CM0 = FULL & ~RM0, CMM = FULL & ~RMM, CML = FULL & ~RML, CMIO = FULL & ~IO_RM;
+        const uint32_t ebase0 = pdep<CM0>(tid), ebaseM = pdep<CMM>(tid), ebaseL = pdep<CML>(tid), ebaseIO = pdep<CMIO>(tid);
+        const uint32_t ntiles = (nb + PPB - 1) / PPB;
+        for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+            const uint32_t b = tile * PPB + pl;
+            const uint32_t bc = b < nb ? b : nb - 1;  // clamped index for the reads of a ragged tail
+            const T *tb = terms + (((size_t)bc * nterms) << LOGN);
+            T acc[NOUT][E];
+            static_for<0, NOUT>([&](auto o) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) acc[o.value][e] = 0;
+            });
+            T r[E];
+            FB::template gather<IO_RM>(r, tb, ebaseIO, false);
+            for (uint32_t j = 0; j < nterms; ++j) {
+                const uint32_t jn = j + 1 < nterms ? j + 1 : j;  // last iteration: harmless re-read
+                T nx[E];
+                FB::template gather<IO_RM>(nx, tb + ((size_t)jn << LOGN), ebaseIO, false);
+                if constexpr (RM0 != IO_RM) {
+                    FB::template scatter<IO_RM>(r, lds, ebaseIO, true);
+                    F::wsync();
+                    FB::template gather<RM0>(r, (const T *)lds, ebase0, true);
+                    F::wsync();
+                }
+                F::template pass<0>(r, lds, tid, twf, imgf, P);  // canonical NTT-domain values, layout RMM
+                static_for<0, NOUT>([&](auto o) {
+                    mul_acc_key(acc[o.value], r, key_ntt + (((size_t)j * NOUT + o.value) << LOGN), ebaseM, P);
+                });
+                F::wsync();  // the forward transform's last exchange has been read before LDS is reused
+#pragma unroll
+                for (int e = 0; e < E; ++e) r[e] = nx[e];
+            }
+            static_for<0, NOUT>([&](auto o) {
+                T(&a)[E] = acc[o.value];
+                I::template pass<0>(a, lds, tid, twi, imgi, P);  // canonical coefficients, layout RML
+                if constexpr (RML != IO_RM) {
+                    F::wsync();
+                    FB::template scatter<RML>(a, lds, ebaseL, true);
+                    F::wsync();
+                    FB::template gather<IO_RM>(a, (const T *)lds, ebaseIO, true);
+                }
+                T *dst = out + (((size_t)bc * NOUT + o.value) << LOGN);
+                if (accumulate) {
+                    T old[E];
+                    FB::template gather<IO_RM>(old, (const T *)dst, ebaseIO, false);
+#pragma unroll
+                    for (int e = 0; e < E; ++e) a[e] = add_mod<T>(old[e], a[e], P.p);
+                }
+                if (b < nb) FB::template scatter<IO_RM>(a, dst, ebaseIO, false);
+                F::wsync();
+            });
+        }
+    }
+};
+
+template <class T, int LOGN, int CLS, int WPB, int WPW, int NOUT>
+__global__ __launch_bounds__(WPB, WPW) void ext_kernel_wp(T *__restrict__ out, const T *__restrict__ terms,
+                                                      const T *__restrict__ key_ntt, const TwPair<T> *__restrict__ twf,
+                                                      const TwPair<T> *__restrict__ twi, const ModParams<T> P,
+                                                      uint32_t nb, uint32_t nterms, uint32_t accumulate) {
+    using K = ExtWp<T, LOGN, CLS, WPB, NOUT>;
+    __shared__ __attribute__((aligned(16))) T lds[(size_t)K::PPB << LOGN];
+    __shared__ __attribute__((aligned(16))) TwPair<T> imgf[K::FB::IMG_ENTRIES];
+    __shared__ __attribute__((aligned(16))) TwPair<T> imgi[K::IB::IMG_ENTRIES];
+    K::run(out, terms, key_ntt, twf, twi, P, nb, nterms, accumulate != 0, lds, imgf, imgi);
 }
 
 template <class T, int LOGN, bool INV, int CLS, bool SUB, int LAB = 0>

@@ -29,4 +29,11 @@ template <class T>
 hipError_t launch_mul_ntt(int logn, int cls, T *lhs, const T *rhs_ntt, const TwPair<T> *twf, const TwPair<T> *twi,
                           const ModParams<T> &P, uint32_t nsub, hipStream_t stream);
 
+// Fused mul_accumulate chain (ExtWp): out[b][o] (+)= inv(sum_j fwd(terms[b][j]) . key_ntt[j][o]), o < nout <= 4.
+// Same eligibility as launch_mul_ntt; hipErrorNotSupported otherwise (the caller composes batched launches).
+template <class T>
+hipError_t launch_ext_ntt(int logn, int cls, T *out, const T *terms, const T *key_ntt, const TwPair<T> *twf,
+                          const TwPair<T> *twi, const ModParams<T> &P, uint32_t batch, uint32_t nterms, uint32_t nout,
+                          bool accumulate, hipStream_t stream);
+
 }  // namespace cntt

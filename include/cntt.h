@@ -100,6 +100,16 @@ int cntt_prime64_mul_accumulate_batch(const cntt_plan64_t *plan, uint64_t *acc, 
  * i.e. the negacyclic product of lhs with the polynomial whose forward transform is rhs_ntt, in one pass over HBM
  * for n <= 1024 (three launches otherwise).  Same values as the three separate calls. */
 int cntt_prime64_mul_ntt_batch(const cntt_plan64_t *plan, uint64_t *lhs, const uint64_t *rhs_ntt, size_t batch, cntt_mem_t where, void *stream);
+/* Fused mul_accumulate chain, the composition a caller of the reference writes around the NTT as
+ *     for j < nterms { plan.fwd(t_j); for o < nout { plan.mul_accumulate(acc_o, t_j, key[j][o]) } }  for o { plan.inv(acc_o) }
+ * (Plan::fwd src/prime64.rs:794, Plan::mul_accumulate :1085-1128, Plan::inv :872) with acc_o starting at zero:
+ *     out[b][o] = inv( sum_j fwd(terms[b][j]) (.) key_ntt[j][o] )            accumulate == 0
+ *     out[b][o] = (out[b][o] + that) mod p                                   accumulate != 0
+ * terms: batch x nterms polynomials (standard domain, element b's terms back to back); key_ntt: nterms x nout
+ * polynomials in the NTT domain, shared by the whole batch; out: batch x nout polynomials.  Same values as the
+ * separate calls (like them, the result carries the factor n of the unnormalised inverse).  One pass over HBM when
+ * the transform fits one wavefront group (n <= 1024 for u64, 4096 for u32) and nout <= 4; composed launches otherwise. */
+int cntt_prime64_external_product_batch(const cntt_plan64_t *plan, uint64_t *out, const uint64_t *terms, const uint64_t *key_ntt, size_t nterms, size_t nout, size_t batch, int accumulate, cntt_mem_t where, void *stream);
 
 /* ===================================================================================== */
 /* prime32::Plan  (src/prime32.rs:601-616)                                                */
@@ -126,6 +136,7 @@ int cntt_prime32_mul_assign_normalize_batch(const cntt_plan32_t *plan, uint32_t 
 int cntt_prime32_normalize_batch(const cntt_plan32_t *plan, uint32_t *values, size_t batch, cntt_mem_t where, void *stream);
 int cntt_prime32_mul_accumulate_batch(const cntt_plan32_t *plan, uint32_t *acc, const uint32_t *lhs, const uint32_t *rhs, size_t batch, cntt_mem_t where, void *stream);
 int cntt_prime32_mul_ntt_batch(const cntt_plan32_t *plan, uint32_t *lhs, const uint32_t *rhs_ntt, size_t batch, cntt_mem_t where, void *stream); /* see cntt_prime64_mul_ntt_batch */
+int cntt_prime32_external_product_batch(const cntt_plan32_t *plan, uint32_t *out, const uint32_t *terms, const uint32_t *key_ntt, size_t nterms, size_t nout, size_t batch, int accumulate, cntt_mem_t where, void *stream); /* see cntt_prime64_external_product_batch */
 
 /* ===================================================================================== */
 /* native / native_binary plans                                                          */
