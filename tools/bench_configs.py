@@ -94,8 +94,37 @@ def product_case(n, primes, batch, tag):
          timed(lambda: plan.inv_batch(std, ntt, product.InvMode.Accumulate), 10), batch, "poly/s", by + n * 8 * batch)
 
 
+def ext_case(mod, bits, n, p, J, O, batch, tag):
+    plan = mod.Plan.try_new(n, p)
+    dt = torch.int64 if bits == 64 else torch.int32
+    terms = torch.empty(batch * J * n, dtype=dt, device="cuda")
+    key = torch.empty(J * O * n, dtype=dt, device="cuda")
+    out = torch.zeros(batch * O * n, dtype=dt, device="cuda")
+    cntt.fill_uniform(terms, p, 3)
+    cntt.fill_uniform(key, p, 4)
+    w = bits // 8
+    ms = timed(lambda: plan.external_product_batch(out, terms, key, J, O), 10)
+    emit("%s fused chain N=%d J=%d O=%d batch=%d" % (tag, n, J, O, batch), ms, (J + O) * batch, "NTT/s",
+         (J + O) * n * w * batch)
+    # the same work as separate calls: J fwd, J*O mul_accumulate, O inv per element (timed per kind, summed)
+    t1 = terms[: batch * n].clone()
+    acc = torch.zeros_like(t1)
+    kk = torch.empty_like(t1)
+    cntt.fill_uniform(kk, p, 5)
+    f = timed(lambda: plan.fwd_batch(t1), 10)
+    m = timed(lambda: plan.mul_accumulate_batch(acc, t1, kk), 10)
+    i = timed(lambda: plan.inv_batch(t1), 10)
+    sep = J * f + J * O * m + O * i
+    emit("%s separate calls (J fwd + J*O mul_accumulate + O inv) N=%d J=%d O=%d batch=%d" % (tag, n, J, O, batch), sep,
+         (J + O) * batch, "NTT/s", (2 * J + 3 * J * O + 2 * O) * n * w * batch)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["p64", "p32", "c4", "c3", "c5", "prod"]
+    which = sys.argv[1:] or ["p64", "p32", "c4", "c3", "c5", "prod", "ext"]
+    if "ext" in which:
+        ext_case(prime64, 64, 1024, P62, 6, 2, 8192, "prime64 external product")
+        ext_case(prime64, 64, 1024, P62, 12, 3, 4096, "prime64 external product")
+        ext_case(prime32, 32, 2048, P30, 6, 2, 8192, "prime32 external product")
     if "prod" in which:
         product_case(2048, [4294955009, 4294914049], 32768, "product u32x2")
         product_case(2048, [18446744069414584321], 32768, "product u64x1 (Solinas)")
