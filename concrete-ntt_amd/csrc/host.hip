@@ -168,12 +168,17 @@ template <class T, class PlanT> static int plan_new(size_t n, T p, PlanT **out) 
     const uint64_t r1 = (uint64_t)(R % p64);
     const uint64_t r2 = host::mulmod(r1, r1, p64);
     mp.r2 = (T)r2;
+    const uint64_t w_last = host::mulmod((uint64_t)pl->inv_twid[1], (uint64_t)pl->n_inv, p64);  // inv_twid[1] / N
     if (mp.cls == CLS_GENERIC) {
         mp.n_inv = (T)host::mulmod((uint64_t)pl->n_inv, r2, p64);  // N^-1 * R^2 (see mul_normalize)
         mp.n_inv_shoup = 0;
+        mp.last_w = (T)host::mulmod(w_last, r2, p64);
+        mp.last_w_shoup = 0;
     } else {
         mp.n_inv = pl->n_inv;
         mp.n_inv_shoup = pl->n_inv_shoup;
+        mp.last_w = (T)w_last;
+        mp.last_w_shoup = shoup_of<T>((T)w_last, p);
     }
     pl->cache = std::make_shared<DeviceCache<T>>();
     *out = pl;

@@ -35,6 +35,8 @@ template <class T> struct ModParams {
     T n_inv, n_inv_shoup;  // N^-1 mod p and its Shoup companion (GENERIC: N^-1 * 2^B mod p, unused)
     T p_barrett;           // floor(2^(big_q + B - 1) / p)   (src/prime64.rs:754-756)
     T r2;                  // 2^(2B) mod p (GENERIC pointwise)
+    T last_w, last_w_shoup; // inv_twid[1] * N^-1 mod p and its Shoup companion (GENERIC: * 2^(2B), unused): the
+                           // fused product kernel normalises inside the last inverse stage (Bfly::inv_norm)
     uint32_t big_q;        // floor(log2 p) + 1
     uint32_t cls;
 };
@@ -203,6 +205,19 @@ template <class T, int CLS> struct Bfly {
             y = mont_mul(sub_mod<T>(x0, y, P.p), w, P.p, P.pinv_neg);
         }
     }
+    // last inverse stage with the 1/N normalisation folded in: (x, y) <- ((x + y) / N, (x - y) w / N).
+    // w = inv_twid[1] for every butterfly of that stage, so P.last_w = w / N replaces the twiddle and only the
+    // sum branch pays one extra product (N/2 per polynomial instead of the N of a separate normalize pass).
+    static __device__ __forceinline__ void inv_norm(T &x, T &y, const ModParams<T> &P) {
+        inv(x, y, P.last_w, P.last_w_shoup, P);
+        if constexpr (CLS == CLS_LAZY) {
+            x = shoup_mul<T>(x, P.n_inv, P.n_inv_shoup, P.neg_p);  // [0, 2p)
+        } else if constexpr (CLS == CLS_STRICT) {
+            x = csub<T>(shoup_mul<T>(x, P.n_inv, P.n_inv_shoup, P.neg_p), P.p);
+        } else {
+            x = mont_mul(x, P.n_inv, P.p, P.pinv_neg);  // n_inv field = N^-1 R^2: x / R * (N^-1 R^2) / R ... see mul_for_inv
+        }
+    }
     // bring a value left by the last stage into [0, p)
     static __device__ __forceinline__ T finish_fwd(T v, const ModParams<T> &P) {
         if constexpr (CLS == CLS_LAZY) return csub<T>(csub_two_p<T>(v, P.two_p, P.neg_two_p), P.p);
@@ -253,6 +268,17 @@ template <class T> __device__ __forceinline__ T mul_normalize(T a, T b, const Mo
     const T prod = barrett_mul_lazy<T>(a, b, P);
     const T t = prod * P.n_inv - mulhi(prod, P.n_inv_shoup) * P.p;
     return csub<T>(t, P.p);
+}
+// a*b in the range the inverse butterflies of class CLS accept, WITHOUT the 1/N factor (Bfly::inv_norm applies it):
+// LAZY [0, 2p); STRICT canonical; GENERIC a b / R canonical (inv_norm's constants carry the R^2).
+template <class T, int CLS> __device__ __forceinline__ T mul_for_inv(T a, T b, const ModParams<T> &P) {
+    if constexpr (CLS == CLS_GENERIC) {
+        return mont_mul(a, b, P.p, P.pinv_neg);
+    } else if constexpr (CLS == CLS_STRICT) {
+        return csub<T>(barrett_mul_lazy<T>(a, b, P), P.p);
+    } else {
+        return barrett_mul_lazy<T>(a, b, P);
+    }
 }
 template <class T> __device__ __forceinline__ T normalize1(T a, const ModParams<T> &P, bool generic) {
     if (generic) {

@@ -282,7 +282,9 @@ struct NttKernel {
         }
     }
 
-    template <int K, int GI, bool IMG = false>
+    // NORM (inverse only): the stage on the top index bit -- the last one, one twiddle inv_twid[1] for all of its
+    // butterflies -- also applies the 1/N normalisation (Bfly::inv_norm).
+    template <int K, int GI, bool IMG = false, bool NORM = false>
     static __device__ __forceinline__ void stage(T (&r)[E], uint32_t ebase, uint32_t qpre, uint32_t depth,
                                                  const TwPair<T> *__restrict__ tw, const ModParams<T> &P,
                                                  uint32_t tid = 0, const TwPair<T> *img = nullptr) {
@@ -294,6 +296,15 @@ struct NttKernel {
         uint32_t toff = (1u << (LOGN - 1 - b)) << (SUB ? depth : 0u);
         if constexpr ((CM >> (b + 1)) != 0u) toff += ebase >> (b + 1);
         if constexpr (SUB) toff += qpre >> (b + 1);
+        if constexpr (NORM && INV && b == LOGN - 1) {
+            static_assert(!SUB, "the normalising stage is the last stage of a whole transform");
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                if ((j >> k) & 1) continue;
+                Bfly<T, CLS>::inv_norm(r[j], r[j | (1 << k)], P);
+            }
+            return;
+        }
         TwPair<T> w[NHI];
 #pragma unroll
         for (int h = 0; h < NHI; ++h) {
@@ -316,13 +327,13 @@ struct NttKernel {
         }
     }
 
-    template <int K, int GI = 0, bool IMG = false>
+    template <int K, int GI = 0, bool IMG = false, bool NORM = false>
     static __device__ __forceinline__ void stages(T (&r)[E], uint32_t ebase, uint32_t qpre, uint32_t depth,
                                                   const TwPair<T> *__restrict__ tw, const ModParams<T> &P,
                                                   uint32_t tid = 0, const TwPair<T> *img = nullptr) {
         if constexpr (GI < cpop(S::GMASK[K])) {
-            stage<K, GI, IMG>(r, ebase, qpre, depth, tw, P, tid, img);
-            stages<K, GI + 1, IMG>(r, ebase, qpre, depth, tw, P, tid, img);
+            stage<K, GI, IMG, NORM>(r, ebase, qpre, depth, tw, P, tid, img);
+            stages<K, GI + 1, IMG, NORM>(r, ebase, qpre, depth, tw, P, tid, img);
         }
     }
 
@@ -410,18 +421,18 @@ struct NttWp : NttKernel<T, LOGN, INV, CLS, false, 0> {
         }
     }
 
-    template <int K>
+    template <int K, bool NORM = false>
     static __device__ __forceinline__ void pass(T (&r)[E], T *lds, uint32_t tid, const TwPair<T> *__restrict__ tw,
                                                 const TwPair<T> *img, const ModParams<T> &P) {
         constexpr uint32_t RM = S::RMASK[K], CM = FULL & ~RM;
         const uint32_t ebase = pdep<CM>(tid);
         if constexpr (K > 0) B::template gather<RM>(r, (const T *)lds, ebase, true);
-        B::template stages<K, 0, true>(r, ebase, 0u, 0u, tw, P, tid, img);
+        B::template stages<K, 0, true, NORM>(r, ebase, 0u, 0u, tw, P, tid, img);
         if constexpr (K < NPASS - 1) {
             if constexpr (K > 0) wsync();
             B::template scatter<RM>(r, lds, ebase, true);
             wsync();
-            pass<K + 1>(r, lds, tid, tw, img, P);
+            pass<K + 1, NORM>(r, lds, tid, tw, img, P);
         } else {
 #pragma unroll
             for (int j = 0; j < E; ++j) r[j] = INV ? Bfly<T, CLS>::finish_inv(r[j], P) : Bfly<T, CLS>::finish_fwd(r[j], P);
@@ -532,7 +543,6 @@ struct MulWp {
         constexpr uint32_t CM0 = FULL & ~RM0, CMM = FULL & ~RMM, CML = FULL & ~RML, CMIO = FULL & ~IO_RM;
         const uint32_t ebase0 = pdep<CM0>(tid), ebaseM = pdep<CMM>(tid), ebaseL = pdep<CML>(tid), ebaseIO = pdep<CMIO>(tid);
         const uint32_t ntiles = (nsub + PPB - 1) / PPB;
-        const bool generic = CLS == CLS_GENERIC;
         T r[E];
 #pragma unroll
         for (int j = 0; j < E; ++j) r[j] = 0;
@@ -561,10 +571,10 @@ struct MulWp {
                 T b[E];
                 FB::template gather<RMM>(b, rhs_ntt + ((size_t)subc << LOGN), ebaseM, false);
 #pragma unroll
-                for (int j = 0; j < E; ++j) r[j] = mul_normalize<T>(r[j], b[j], P, generic);
+                for (int j = 0; j < E; ++j) r[j] = mul_for_inv<T, CLS>(r[j], b[j], P);  // 1/N: inside the last inverse stage
             }
             F::wsync();  // the forward transform's last exchange has been read before the inverse overwrites it
-            I::template pass<0>(r, lds, tid, twi, imgi, P);  // canonical coefficients, layout RML
+            I::template pass<0, true>(r, lds, tid, twi, imgi, P);  // canonical coefficients, layout RML
             if constexpr (RML != IO_RM) {
                 F::wsync();
                 FB::template scatter<RML>(r, lds, ebaseL, true);
