@@ -1040,12 +1040,11 @@ static int product_ntt_device(const cntt_product *pl, ProductView v, size_t batc
     return CNTT_OK;
 }
 
-// Plan::fwd src/product.rs:273-357  (device pointers)
-static int product_fwd_device(const cntt_product *pl, uint64_t *ntt, const uint64_t *standard, size_t batch,
-                              bool bounded, uint64_t bound, hipStream_t st) {
+// residue split of `batch` polynomials into the plane-major view v (the first half of Plan::fwd, src/product.rs:282-355)
+static int product_split_device(const cntt_product *pl, ProductView v, const uint64_t *standard, size_t batch, bool bounded,
+                                uint64_t bound, hipStream_t st) {
     const size_t count = batch * pl->n, k = pl->primes.size();
     if (count == 0 || k == 0) return CNTT_OK;
-    const ProductView v = product_view(pl, ntt, batch);
     ProductArgs A = pl->args;
     A.bound = bound;
     const dim3 grid(ew_grid(count / 2)), block(256);
@@ -1056,6 +1055,15 @@ static int product_fwd_device(const cntt_product *pl, uint64_t *ntt, const uint6
     else
         hipLaunchKernelGGL((product_split_kernel<0>), grid, block, 0, st, v.r32, v.r64, standard, A, count);
     HIP_TRY(hipGetLastError());
+    return CNTT_OK;
+}
+
+// Plan::fwd src/product.rs:273-357  (device pointers)
+static int product_fwd_device(const cntt_product *pl, uint64_t *ntt, const uint64_t *standard, size_t batch,
+                              bool bounded, uint64_t bound, hipStream_t st) {
+    if (batch == 0 || pl->primes.empty()) return CNTT_OK;
+    const ProductView v = product_view(pl, ntt, batch);
+    if (int rc = product_split_device(pl, v, standard, batch, bounded, bound, st)) return rc;
     return product_ntt_device(pl, v, batch, false, st);
 }
 
@@ -1068,17 +1076,11 @@ static void launch_product_crt(uint64_t *standard, ProductView v, const ProductA
     else hipLaunchKernelGGL((product_crt_kernel<K, 2>), grid, block, 0, st, standard, v.r32, v.r64, A, count);
 }
 
-// Plan::inv src/product.rs:360-879  (device pointers)
-static int product_inv_device(const cntt_product *pl, uint64_t *standard, uint64_t *ntt, size_t batch, bool accumulate,
+// Garner recombination of `batch` polynomials from the plane-major view v (the second half of Plan::inv, src/product.rs:386-879)
+static int product_crt_device(const cntt_product *pl, uint64_t *standard, ProductView v, size_t batch, bool accumulate,
                               hipStream_t st) {
     const size_t count = batch * pl->n, k = pl->primes.size();
     if (count == 0) return CNTT_OK;
-    if (k == 0) {  // src/product.rs:378-384
-        if (!accumulate) HIP_TRY(hipMemsetAsync(standard, 0, count * 8, st));
-        return CNTT_OK;
-    }
-    const ProductView v = product_view(pl, ntt, batch);
-    if (int rc = product_ntt_device(pl, v, batch, true, st)) return rc;
     const int acc = !accumulate ? 0 : (k == 1 && pl->p32.size() == 1 ? 2 : 1);
     switch (k) {
     case 1: launch_product_crt<1>(standard, v, pl->args, count, acc, st); break;
@@ -1091,6 +1093,51 @@ static int product_inv_device(const cntt_product *pl, uint64_t *standard, uint64
     }
     HIP_TRY(hipGetLastError());
     return CNTT_OK;
+}
+
+// Plan::inv src/product.rs:360-879  (device pointers)
+static int product_inv_device(const cntt_product *pl, uint64_t *standard, uint64_t *ntt, size_t batch, bool accumulate,
+                              hipStream_t st) {
+    const size_t count = batch * pl->n;
+    if (count == 0) return CNTT_OK;
+    if (pl->primes.empty()) {  // src/product.rs:378-384
+        if (!accumulate) HIP_TRY(hipMemsetAsync(standard, 0, count * 8, st));
+        return CNTT_OK;
+    }
+    const ProductView v = product_view(pl, ntt, batch);
+    if (int rc = product_ntt_device(pl, v, batch, true, st)) return rc;
+    return product_crt_device(pl, standard, v, batch, accumulate, st);
+}
+
+// The external-product step of the reference's caller at the product::Plan level (device pointers):
+//     for j { plan.fwd(t_j, terms[b][j], fwd_mode); for o { plan.mul_accumulate(acc_o, t_j, key[j][o]) } }
+//     for o { plan.inv(out[b][o], acc_o, inv_mode) }
+// = residue split of all terms, one fused mul_accumulate chain per prime plane, one Garner recombination.
+static int product_external_product_device(const cntt_product *pl, uint64_t *out, const uint64_t *terms, const uint64_t *key,
+                                           size_t nterms, size_t nout, size_t batch, bool bounded, uint64_t bound,
+                                           bool accumulate, hipStream_t st) {
+    if (batch == 0 || nout == 0) return CNTT_OK;
+    const size_t n = pl->n, dl = pl->domain_len();
+    if (pl->primes.empty() || nterms == 0) {
+        if (!accumulate) HIP_TRY(hipMemsetAsync(out, 0, batch * nout * n * 8, st));
+        return CNTT_OK;
+    }
+    const size_t tpolys = batch * nterms, opolys = batch * nout, kpolys = nterms * nout;
+    uint64_t *scratch = nullptr;
+    HIP_TRY(hipMallocAsync((void **)&scratch, (tpolys + opolys) * dl * 8, st));
+    uint64_t *tres = scratch, *ores = scratch + tpolys * dl;
+    const ProductView tv = product_view(pl, tres, tpolys), ov = product_view(pl, ores, opolys);
+    const ProductView kv = product_view(pl, const_cast<uint64_t *>(key), kpolys);
+    int rc = product_split_device(pl, tv, terms, tpolys, bounded, bound, st);
+    for (size_t i = 0; i < pl->p32.size() && rc == CNTT_OK; ++i)
+        rc = external_product_device<uint32_t>(pl->p32[i].get(), ov.r32 + i * opolys * n, tv.r32 + i * tpolys * n,
+                                               kv.r32 + i * kpolys * n, nterms, nout, batch, false, st);
+    for (size_t i = 0; i < pl->p64.size() && rc == CNTT_OK; ++i)
+        rc = external_product_device<uint64_t>(pl->p64[i].get(), ov.r64 + i * opolys * n, tv.r64 + i * tpolys * n,
+                                               kv.r64 + i * kpolys * n, nterms, nout, batch, false, st);
+    if (rc == CNTT_OK) rc = product_crt_device(pl, out, ov, opolys, accumulate, st);
+    (void)hipFreeAsync(scratch, st);
+    return rc;
 }
 
 // op 2 mul_assign_normalize, 3 normalize, 4 mul_accumulate, per prime on the plane-major layout: src/product.rs:885-966
@@ -1214,4 +1261,33 @@ extern "C" int cntt_product_normalize_batch(const cntt_product_t *pl, uint64_t *
 extern "C" int cntt_product_mul_accumulate_batch(const cntt_product_t *pl, uint64_t *acc, const uint64_t *lhs,
                                                  const uint64_t *rhs, size_t batch, cntt_mem_t where, void *stream) {
     return product_op(pl, 4, acc, const_cast<uint64_t *>(lhs), rhs, batch, 0, 0, where, (hipStream_t)stream);
+}
+
+extern "C" int cntt_product_external_product_batch(const cntt_product_t *pl, uint64_t *out, const uint64_t *terms,
+                                                   const uint64_t *key_ntt, size_t nterms, size_t nout, size_t batch,
+                                                   cntt_fwd_mode_t fwd_mode, uint64_t bound, cntt_inv_mode_t inv_mode,
+                                                   cntt_mem_t where, void *stream) {
+    if (!pl) return fail(CNTT_EINVAL, "plan is NULL");
+    if (batch == 0 || nout == 0) return CNTT_OK;
+    const size_t n = pl->n, dl = pl->domain_len();
+    if (!out || (nterms && (!terms || (dl && !key_ntt)))) return fail(CNTT_EINVAL, "NULL buffer");
+    if (batch * std::max(nterms, nout) * n >= ((size_t)1 << 40)) return fail(CNTT_EINVAL, "batch too large");
+    hipStream_t st = (hipStream_t)stream;
+    const bool bounded = fwd_mode == CNTT_FWD_BOUNDED, accumulate = inv_mode == CNTT_INV_ACCUMULATE;
+    if (where == CNTT_MEM_DEVICE)
+        return product_external_product_device(pl, out, terms, key_ntt, nterms, nout, batch, bounded, bound, accumulate, st);
+    const size_t ob = batch * nout * n * 8, tb = batch * nterms * n * 8, kb = nterms * nout * dl * 8;
+    DevBuf dout, dt, dk;
+    if (int rc = dout.alloc(ob)) return rc;
+    if (int rc = dt.alloc(tb)) return rc;
+    if (int rc = dk.alloc(kb)) return rc;
+    if (accumulate) HIP_TRY(hipMemcpyAsync(dout.p, out, ob, hipMemcpyHostToDevice, st));
+    if (tb) HIP_TRY(hipMemcpyAsync(dt.p, terms, tb, hipMemcpyHostToDevice, st));
+    if (kb) HIP_TRY(hipMemcpyAsync(dk.p, key_ntt, kb, hipMemcpyHostToDevice, st));
+    if (int rc = product_external_product_device(pl, (uint64_t *)dout.p, (const uint64_t *)dt.p, (const uint64_t *)dk.p, nterms,
+                                                 nout, batch, bounded, bound, accumulate, st))
+        return rc;
+    HIP_TRY(hipMemcpyAsync(out, dout.p, ob, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return CNTT_OK;
 }

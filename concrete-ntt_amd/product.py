@@ -189,3 +189,15 @@ class Plan:
         lp, _, _, _ = self._dom(lhs, batch, where)
         rp, _, _, _ = self._dom(rhs, batch, where)
         check(lib().cntt_product_mul_accumulate_batch(self._h, ap, lp, rp, batch, where, stream))
+
+    def external_product_batch(self, out, terms, key_ntt, nterms, nout, fwd_mode=FwdMode.Generic, inv_mode=InvMode.Replace):
+        """out[b][o] (+)= inv(sum_j fwd(terms[b][j]) . key_ntt[j][o]): the values of Plan.fwd / mul_accumulate / inv
+        (src/product.rs:273, :935, :360) called in sequence -- split, one fused chain per prime, Garner."""
+        op, ob, where, stream = self._std(out)
+        tp, tb, tw, _ = self._std(terms)
+        if nout <= 0 or ob % nout or tb != (ob // nout) * nterms or tw != where:
+            raise Panic("out: batch*nout, terms: batch*nterms polynomials in the same memory")
+        kp, _, _, _ = self._dom(key_ntt, nterms * nout, where)
+        m, bound = self._mode(fwd_mode)
+        check(lib().cntt_product_external_product_batch(self._h, op, tp, kp, nterms, nout, ob // nout, m, bound,
+                                                        int(inv_mode), where, stream))

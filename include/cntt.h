@@ -235,6 +235,15 @@ int cntt_product_inv_batch(const cntt_product_t *plan, uint64_t *standard, uint6
 int cntt_product_mul_assign_normalize_batch(const cntt_product_t *plan, uint64_t *lhs, const uint64_t *rhs, size_t batch, cntt_mem_t where, void *stream);
 int cntt_product_normalize_batch(const cntt_product_t *plan, uint64_t *values, size_t batch, cntt_mem_t where, void *stream);
 int cntt_product_mul_accumulate_batch(const cntt_product_t *plan, uint64_t *acc, const uint64_t *lhs, const uint64_t *rhs, size_t batch, cntt_mem_t where, void *stream);
+/* The external-product step of the reference's caller (tfhe-rs NTT backend) in one call:
+ *     for j < nterms { plan.fwd(t_j, terms[b][j], fwd_mode); for o < nout { plan.mul_accumulate(acc_o, t_j, key[j][o]) } }
+ *     for o { plan.inv(out[b][o], acc_o, inv_mode) }                    (acc_o starts at zero)
+ * terms: batch x nterms polynomials of n words (standard domain, element b's terms back to back); key_ntt: nterms x nout
+ * polynomials in the NTT domain in the plane-major batched layout above (i.e. what cntt_product_fwd_batch writes for a
+ * batch of nterms*nout polynomials, key[j][o] at batch index j*nout + o); out: batch x nout polynomials of n words.
+ * Same values as the separate calls.  Runs as: one residue split, one fused mul_accumulate chain per prime
+ * (cntt_prime*_external_product_batch), one Garner recombination; residues live in a stream-ordered scratch buffer. */
+int cntt_product_external_product_batch(const cntt_product_t *plan, uint64_t *out, const uint64_t *terms, const uint64_t *key_ntt, size_t nterms, size_t nout, size_t batch, cntt_fwd_mode_t fwd_mode, uint64_t bound, cntt_inv_mode_t inv_mode, cntt_mem_t where, void *stream);
 
 /* ===================================================================================== */
 /* utilities (not part of the reference API)                                              */

@@ -381,3 +381,61 @@ def test_gpu_product_length_panics(oracle):
     s = np.arange(64, dtype=np.uint64)
     empty.inv(s, np.zeros(0, dtype=np.uint64), product.InvMode.Replace)
     assert not s.any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["u32x2", "u64x1", "u32x2_u64x1", "u30x2"])
+@pytest.mark.parametrize("accumulate", [False, True])
+def test_gpu_product_external_product(oracle, shape, accumulate):
+    """cntt_product_external_product_batch against the oracle's Plan::fwd / mul_accumulate / inv in sequence
+    (src/product.rs:273, :935, :360), Generic and Bounded forward modes, Replace and Accumulate inverse modes."""
+    import torch
+    from concrete_ntt_amd import product
+    n, J, O, batch = 512, 3, 2, 3
+    primes = sorted(_ref_primes(oracle, n, shape))
+    big = 1
+    for p in primes:
+        big *= p
+    plan, oplan = product.Plan.try_new(n, big, primes), oracle.Product.try_new(n, big, primes)
+    n32 = sum(p < 2**32 for p in primes)
+    dl = plan.ntt_domain_len()
+    bound = 1 << 18
+    raw = oracle.fill_uniform(batch * J * n, 2 * bound - 1, 7, 64)
+    terms = np.array([(int(x) - bound + 1) % big for x in raw], dtype=np.uint64)  # centred, |value| < bound
+    init = oracle.fill_uniform(batch * O * n, big, 8, 64)
+    # key: canonical residues per prime, plane-major for a "batch" of J*O polynomials
+    planes = [oracle.fill_uniform(J * O * n, p, 50 + i, 64) for i, p in enumerate(primes)]
+    key32 = np.concatenate([pl_.astype(np.uint32) for pl_ in planes[:n32]]) if n32 else np.zeros(0, dtype=np.uint32)
+    key = np.concatenate([key32.view(np.uint64)] + [pl_ for pl_ in planes[n32:]])
+
+    def key_poly(j, o):  # reference-layout ntt buffer of key[j][o]
+        i = j * O + o
+        parts = []
+        if n32:
+            parts.append(np.concatenate([planes[k][i * n:(i + 1) * n].astype(np.uint32) for k in range(n32)]).view(np.uint64))
+        parts += [planes[k][i * n:(i + 1) * n] for k in range(n32, len(primes))]
+        return np.concatenate(parts)
+
+    for fwd_bound in (None, bound):
+        want = np.zeros(batch * O * n, dtype=np.uint64)
+        for b in range(batch):
+            acc = [np.zeros(dl, dtype=np.uint64) for _ in range(O)]
+            for j in range(J):
+                t = np.zeros(dl, dtype=np.uint64)
+                oplan.fwd(t, terms[(b * J + j) * n:(b * J + j + 1) * n].copy(), fwd_bound)
+                for o in range(O):
+                    oplan.mul_accumulate(acc[o], t, key_poly(j, o))
+            for o in range(O):
+                r = init[(b * O + o) * n:(b * O + o + 1) * n].copy() if accumulate else np.zeros(n, dtype=np.uint64)
+                oplan.inv(r, acc[o], accumulate)
+                want[(b * O + o) * n:(b * O + o + 1) * n] = r
+        mode = product.FwdMode.Generic if fwd_bound is None else product.FwdMode.Bounded(fwd_bound)
+        imode = product.InvMode.Accumulate if accumulate else product.InvMode.Replace
+        dout = torch.from_numpy((init if accumulate else np.zeros_like(init)).view(np.int64).copy()).cuda()
+        dterms = torch.from_numpy(terms.view(np.int64).copy()).cuda()
+        dkey = torch.from_numpy(key.view(np.int64).copy()).cuda()
+        plan.external_product_batch(dout, dterms, dkey, J, O, mode, imode)
+        assert np.array_equal(dout.cpu().numpy().view(np.uint64), want), (shape, fwd_bound)
+        hout = (init if accumulate else np.zeros_like(init)).copy()
+        plan.external_product_batch(hout, terms, key, J, O, mode, imode)   # host-memory call
+        assert np.array_equal(hout, want)
