@@ -98,7 +98,7 @@ int cntt_prime64_mul_accumulate_batch(const cntt_plan64_t *plan, uint64_t *acc, 
 /* Fused lhs <- inv(mul_assign_normalize(fwd(lhs), rhs_ntt)): the composition a caller of the reference writes as
  * plan.fwd(a); plan.mul_assign_normalize(a, b_ntt); plan.inv(a)  (examples/mul_poly_prime.rs, src/prime64.rs:1254-1266),
  * i.e. the negacyclic product of lhs with the polynomial whose forward transform is rhs_ntt, in one pass over HBM
- * for n <= 1024 (three launches otherwise).  Same values as the three separate calls. */
+ * for n <= 2048 (u64) / 4096 (u32), three launches otherwise.  Same values as the three separate calls. */
 int cntt_prime64_mul_ntt_batch(const cntt_plan64_t *plan, uint64_t *lhs, const uint64_t *rhs_ntt, size_t batch, cntt_mem_t where, void *stream);
 /* Fused mul_accumulate chain, the composition a caller of the reference writes around the NTT as
  *     for j < nterms { plan.fwd(t_j); for o < nout { plan.mul_accumulate(acc_o, t_j, key[j][o]) } }  for o { plan.inv(acc_o) }
@@ -108,7 +108,7 @@ int cntt_prime64_mul_ntt_batch(const cntt_plan64_t *plan, uint64_t *lhs, const u
  * terms: batch x nterms polynomials (standard domain, element b's terms back to back); key_ntt: nterms x nout
  * polynomials in the NTT domain, shared by the whole batch; out: batch x nout polynomials.  Same values as the
  * separate calls (like them, the result carries the factor n of the unnormalised inverse).  One pass over HBM when
- * the transform fits one wavefront group (n <= 1024 for u64, 4096 for u32) and nout <= 4; composed launches otherwise. */
+ * the twiddle images fit LDS (n <= 2048 for u64, 4096 for u32) and nout <= 4; composed launches otherwise. */
 int cntt_prime64_external_product_batch(const cntt_plan64_t *plan, uint64_t *out, const uint64_t *terms, const uint64_t *key_ntt, size_t nterms, size_t nout, size_t batch, int accumulate, cntt_mem_t where, void *stream);
 
 /* ===================================================================================== */

@@ -125,6 +125,8 @@ if __name__ == "__main__":
         ext_case(prime64, 64, 1024, P62, 6, 2, 8192, "prime64 external product")
         ext_case(prime64, 64, 1024, P62, 12, 3, 4096, "prime64 external product")
         ext_case(prime32, 32, 2048, P30, 6, 2, 8192, "prime32 external product")
+        ext_case(prime64, 64, 2048, P62, 6, 2, 4096, "prime64 external product")
+        ext_case(prime64, 64, 2048, 18446744069414584321, 6, 2, 4096, "prime64 (Solinas) external product")
     if "prod" in which:
         product_case(2048, [4294955009, 4294914049], 32768, "product u32x2")
         product_case(2048, [18446744069414584321], 32768, "product u64x1 (Solinas)")
@@ -137,6 +139,8 @@ if __name__ == "__main__":
     if "c4" in which:
         prime_case(prime64, 64, 16384, P62, 4096, "prime64 (C4 shard slice)")
         prime_case(prime64, 64, 4096, P62, 16384, "prime64")
+    if "p64n2048" in which:
+        prime_case(prime64, 64, 2048, P62, 32768, "prime64")
     if "c3" in which:
         native_case(native64.Plan32, 4096, 16384, "native64::Plan32 (C3)", False)
     if "c5" in which:
