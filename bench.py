@@ -164,7 +164,7 @@ def main():
     achieved = fused_alg / (fused_ms * 1e-3) / 1e9
     # HBM bytes per launch measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes; FETCH_SIZE
     # doubled on gfx950) for exactly this kernel and batch: profiles/r01_v3_rocprofv3_summary.txt
-    traffic = (2 * 524731.8 + 524288.0) * 1024 if batch == 65536 else None
+    traffic = (2 * 524748.2 + 524288.0) * 1024 if batch == 65536 else None
 
     if rank == 0:
         units = world * 2 * batch * args.steps        # forward + inverse transforms, all ranks
