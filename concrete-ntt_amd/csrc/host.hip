@@ -1122,6 +1122,10 @@ static int product_external_product_device(const cntt_product *pl, uint64_t *out
         if (!accumulate) HIP_TRY(hipMemsetAsync(out, 0, batch * nout * n * 8, st));
         return CNTT_OK;
     }
+    if (pl->primes.size() == 1 && pl->p64.size() == 1)
+        // u64x1 plan: fwd copies (src/product.rs:282-286) and inv copies / add_mod_u64s (:386-398), so the per-prime
+        // chain reads `terms` and writes `out` directly -- no residue buffers at all
+        return external_product_device<uint64_t>(pl->p64[0].get(), out, terms, key, nterms, nout, batch, accumulate, st);
     const size_t tpolys = batch * nterms, opolys = batch * nout, kpolys = nterms * nout;
     uint64_t *scratch = nullptr;
     HIP_TRY(hipMallocAsync((void **)&scratch, (tpolys + opolys) * dl * 8, st));

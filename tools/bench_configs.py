@@ -119,8 +119,31 @@ def ext_case(mod, bits, n, p, J, O, batch, tag):
          (J + O) * batch, "NTT/s", (2 * J + 3 * J * O + 2 * O) * n * w * batch)
 
 
+def product_ext_case(n, primes, J, O, batch, tag):
+    from concrete_ntt_amd import product
+    big = 1
+    for q in primes:
+        big *= q
+    plan = product.Plan.try_new(n, big, primes)
+    terms = torch.empty(batch * J * n, dtype=torch.int64, device="cuda")
+    cntt.fill_uniform(terms, 1 << 20, 3)
+    g = torch.empty(J * O * n, dtype=torch.int64, device="cuda")
+    cntt.fill_uniform(g, big, 4)
+    key = torch.zeros(J * O * plan.ntt_domain_len(), dtype=torch.int64, device="cuda")
+    plan.fwd_batch(key, g)
+    out = torch.zeros(batch * O * n, dtype=torch.int64, device="cuda")
+    for name, mode in (("Generic", product.FwdMode.Generic), ("Bounded", product.FwdMode.Bounded(1 << 20))):
+        ms = timed(lambda: plan.external_product_batch(out, terms, key, J, O, mode, product.InvMode.Accumulate), 10)
+        emit("%s external product (%s, Accumulate) N=%d J=%d O=%d batch=%d" % (tag, name, n, J, O, batch), ms, batch,
+             "ext-products/s", (J + 2 * O) * n * 8 * batch)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["p64", "p32", "c4", "c3", "c5", "prod", "ext"]
+    if "pext" in which:
+        product_ext_case(2048, [4294955009, 4294914049], 6, 2, 4096, "product u32x2")
+        product_ext_case(2048, [18446744069414584321], 6, 2, 4096, "product u64x1 (Solinas)")
+        product_ext_case(1024, [4611686018427322369], 6, 2, 8192, "product u64x1 (62-bit)")
     if "ext" in which:
         ext_case(prime64, 64, 1024, P62, 6, 2, 8192, "prime64 external product")
         ext_case(prime64, 64, 1024, P62, 12, 3, 4096, "prime64 external product")

@@ -18,6 +18,9 @@ static TwPair<uint64_t> *g_tw;
 static ModParams<uint64_t> g_P;
 static const uint32_t BATCH = 65536;
 static const int REPS = 200;
+#ifndef LAB_WPW
+#define LAB_WPW 3  // waves per SIMD the persistent kernel is compiled for (= workgroups of 256 threads per CU)
+#endif
 
 static unsigned long long *g_stamp;  // device buffer, 2 slots per wave
 static const size_t STAMP_WAVES = 65536 + 1024;
@@ -141,11 +144,11 @@ int main() {
     base<7, true>("inv ALU only (1+2+4)");
     {
         std::vector<uint64_t> src(h.begin(), h.begin() + (size_t)1333 * 1024);
-        printf("check wp<256,3> fwd %d inv %d\n", (int)check_wp<256, 3, false>(src, 1333, 7),
-               (int)check_wp<256, 3, true>(src, 1333, 64));
+        printf("check wp<256,LAB_WPW> fwd %d inv %d\n", (int)check_wp<256, LAB_WPW, false>(src, 1333, 7),
+               (int)check_wp<256, LAB_WPW, true>(src, 1333, 64));
     }
-    wp<256, 3, false>("wp 256thr x3/CU fwd", 3);
-    wp<256, 3, false>("wp 256thr x2/CU fwd", 2);
-    wp<256, 3, true>("wp 256thr x3/CU inv", 3);
+    wp<256, LAB_WPW, false, false>("wp 256thr xLAB_WPW/CU fwd", LAB_WPW);
+    wp<256, LAB_WPW, false, false>("wp 256thr x2/CU fwd", 2);
+    wp<256, LAB_WPW, true, false>("wp 256thr xLAB_WPW/CU inv", LAB_WPW);
     return 0;
 }
