@@ -1,0 +1,4 @@
+// fused mul_accumulate-chain kernel instantiations: u32, 3 outputs
+#define INST_T uint32_t
+#define INST_NOUT 3
+#include "ntt_ext_inst.inc"

@@ -29,11 +29,25 @@ template <class T>
 hipError_t launch_mul_ntt(int logn, int cls, T *lhs, const T *rhs_ntt, const TwPair<T> *twf, const TwPair<T> *twi,
                           const ModParams<T> &P, uint32_t nsub, hipStream_t stream);
 
-// Fused mul_accumulate chain (ExtWp): out[b][o] (+)= inv(sum_j fwd(terms[b][j]) . key_ntt[j][o]), o < nout <= 4.
+// Fused mul_accumulate chain (ExtWp): out[b][o] (+)= inv(sum_j fwd(terms[b][j]) . key_ntt[j][o]), o < NOUT <= 4.
 // Same eligibility as launch_mul_ntt; hipErrorNotSupported otherwise (the caller composes batched launches).
+// One explicit specialisation per (T, NOUT), each in its own translation unit (ntt_inst_*_ext<NOUT>.hip).
+template <class T, int NOUT>
+hipError_t launch_ext_ntt_n(int logn, int cls, T *out, const T *terms, const T *key_ntt, const TwPair<T> *twf,
+                            const TwPair<T> *twi, const ModParams<T> &P, uint32_t batch, uint32_t nterms, bool accumulate,
+                            hipStream_t stream);
 template <class T>
-hipError_t launch_ext_ntt(int logn, int cls, T *out, const T *terms, const T *key_ntt, const TwPair<T> *twf,
-                          const TwPair<T> *twi, const ModParams<T> &P, uint32_t batch, uint32_t nterms, uint32_t nout,
-                          bool accumulate, hipStream_t stream);
+inline hipError_t launch_ext_ntt(int logn, int cls, T *out, const T *terms, const T *key_ntt, const TwPair<T> *twf,
+                                 const TwPair<T> *twi, const ModParams<T> &P, uint32_t batch, uint32_t nterms, uint32_t nout,
+                                 bool accumulate, hipStream_t stream) {
+    switch (nout) {
+    case 0: return hipSuccess;
+    case 1: return launch_ext_ntt_n<T, 1>(logn, cls, out, terms, key_ntt, twf, twi, P, batch, nterms, accumulate, stream);
+    case 2: return launch_ext_ntt_n<T, 2>(logn, cls, out, terms, key_ntt, twf, twi, P, batch, nterms, accumulate, stream);
+    case 3: return launch_ext_ntt_n<T, 3>(logn, cls, out, terms, key_ntt, twf, twi, P, batch, nterms, accumulate, stream);
+    case 4: return launch_ext_ntt_n<T, 4>(logn, cls, out, terms, key_ntt, twf, twi, P, batch, nterms, accumulate, stream);
+    default: return hipErrorNotSupported;
+    }
+}
 
 }  // namespace cntt
