@@ -472,3 +472,56 @@ def test_c3_c5_native_full_n(oracle):
         dp = to_dev(np.zeros_like(lhs))
         plan.negacyclic_polymul_batch(dp, to_dev(lhs), to_dev(rhs))
         assert np.array_equal(to_host(dp, np.uint64), want), kind
+
+
+def test_batch_calls_capture_into_a_hip_graph(oracle):
+    """Device-resident _batch calls only enqueue (no allocation, no synchronisation), so a launch-bound sequence can be
+    captured once into a hipGraph and replayed: fwd -> mul_assign_normalize -> inv, the fused mul_ntt, and a native
+    polymul whose workspace was reserved beforehand.  Replays are checked against the oracle."""
+    torch = _torch()
+    n, batch = 256, 6
+    plan, oplan = prime64.Plan.try_new(n, P62), oracle.Plan.try_new(n, P62, 64)
+    a = oracle.fill_uniform(batch * n, P62, 77, 64)
+    b = oracle.fill_uniform(batch * n, P62, 78, 64)
+    fb = b.copy()
+    want = a.copy()
+    for i in range(batch):
+        oplan.fwd(fb[i * n:(i + 1) * n])
+        oplan.fwd(want[i * n:(i + 1) * n])
+    oplan.mul_assign_normalize(want, fb)
+    for i in range(batch):
+        oplan.inv(want[i * n:(i + 1) * n])
+    nplan = native64.Plan32.try_new(n)
+    nplan.reserve(batch)
+    lhs = oracle.fill_uniform(batch * n, 0, 79, 64)
+    rhs = oracle.fill_uniform(batch * n, 0, 80, 64)
+    src, dfb = to_dev(a), to_dev(fb)
+    x, y = torch.empty_like(src), torch.empty_like(src)
+    dl, dr, dp = to_dev(lhs), to_dev(rhs), torch.empty_like(src)
+    # warm every kernel and table upload outside the capture
+    x.copy_(src); plan.fwd_batch(x); plan.mul_assign_normalize_batch(x, dfb); plan.inv_batch(x)
+    y.copy_(src); plan.mul_ntt_batch(y, dfb)
+    nplan.negacyclic_polymul_batch(dp, dl, dr)
+    ref_native = to_host(dp, np.uint64).copy()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        x.copy_(src)
+        plan.fwd_batch(x)
+        plan.mul_assign_normalize_batch(x, dfb)
+        plan.inv_batch(x)
+        y.copy_(src)
+        plan.mul_ntt_batch(y, dfb)
+        nplan.negacyclic_polymul_batch(dp, dl, dr)
+    for _ in range(3):
+        x.zero_(); y.zero_(); dp.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(to_host(x, np.uint64), want)
+        assert np.array_equal(to_host(y, np.uint64), want)
+        assert np.array_equal(to_host(dp, np.uint64), ref_native)
+    # the native product itself against the schoolbook wrapping convolution (polynomial 0)
+    onat = oracle.Native("native64_plan32", n)
+    prod0 = np.zeros(n, dtype=np.uint64)
+    onat.negacyclic_polymul(prod0, lhs[:n].copy(), rhs[:n].copy())
+    assert np.array_equal(ref_native[:n], prod0)
