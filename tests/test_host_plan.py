@@ -163,21 +163,22 @@ def _build_examples():
 
 
 def test_c_examples_build_and_fail_loudly_without_gpu():
-    """The C ABI is plain C (gcc -std=c11 -pedantic on examples/*.c) and there is no CPU path: without a GPU the
+    """The C ABI is plain C (gcc -std=c11 -pedantic on examples/*.c), include/cntt.hpp is plain C++17, and there is no CPU path: without a GPU the
     first compute call returns CNTT_EDEVICE and the program says so."""
     _build_examples()
     import torch
     if torch.cuda.is_available():
         pytest.skip("GPU present: covered by test_c_examples_run_on_gpu")
-    for name in ("mul_poly_prime", "mul_poly_native"):
+    for name, needle in (("mul_poly_prime", "status 4"), ("mul_poly_native", "status 4"), ("readme_example", "device error")):
         r = subprocess.run([os.path.join(ROOT, "examples", name)], capture_output=True, text=True)
-        assert r.returncode == 1 and "status 4" in r.stderr, (name, r.returncode, r.stderr)
+        assert r.returncode == 1 and needle in r.stderr, (name, r.returncode, r.stderr)
 
 
 @pytest.mark.gpu
 def test_c_examples_run_on_gpu():
-    """examples/mul_poly_prime.c and mul_poly_native.c (the reference's examples/*.rs through the C ABI)."""
+    """examples/mul_poly_prime.c and mul_poly_native.c (the reference's examples/*.rs through the C ABI) and the
+    README example + a product::Plan round trip through the C++17 mirror include/cntt.hpp."""
     _build_examples()
-    for name in ("mul_poly_prime", "mul_poly_native"):
+    for name in ("mul_poly_prime", "mul_poly_native", "readme_example"):
         r = subprocess.run([os.path.join(ROOT, "examples", name)], capture_output=True, text=True, timeout=120)
         assert r.returncode == 0 and "Success!" in r.stdout, (name, r.returncode, r.stdout, r.stderr)
