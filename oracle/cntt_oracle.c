@@ -1654,6 +1654,146 @@ void orc_product_mul_accumulate(const orc_product *pl, uint64_t *acc, const uint
 }
 
 /* ========================================================================= */
+/* AVX-512 restatement of the 62-bit-class engine (CPU baseline only)        */
+/*   src/prime64/shoup.rs:10-156 (fwd_breadth_first_avx512), :712-870 (inv),  */
+/*   butterflies src/prime64/less_than_62bit.rs:7-57 (fwd) and the inverse    */
+/*   pair; 64x64->128 emulation as src/lib.rs:171-199 (four vpmuludq).        */
+/* Built only where the compiler targets AVX-512F+DQ (the `native` build on  */
+/* the machine that times the baseline); same values as the scalar engine --  */
+/* tests/test_oracle_golden.py compares them when the build has it.          */
+/* ========================================================================= */
+#if defined(__AVX512F__) && defined(__AVX512DQ__)
+#include <immintrin.h>
+int orc_avx512_available(void) { return __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512dq"); }
+
+typedef __m512i v8;
+static inline v8 v_small_mod(v8 m, v8 x) { return _mm512_min_epu64(x, _mm512_sub_epi64(x, m)); }
+/* high 64 bits of the lane-wise 64x64 product: schoolbook on 32-bit halves */
+static inline v8 v_mulhi(v8 a, v8 b) {
+    const v8 mask = _mm512_set1_epi64(0xFFFFFFFFll);
+    v8 ah = _mm512_srli_epi64(a, 32), bh = _mm512_srli_epi64(b, 32);
+    v8 ll = _mm512_mul_epu32(a, b), lh = _mm512_mul_epu32(a, bh), hl = _mm512_mul_epu32(ah, b), hh = _mm512_mul_epu32(ah, bh);
+    v8 mid = _mm512_add_epi64(lh, _mm512_srli_epi64(ll, 32));              /* < 2^64 */
+    v8 mid2 = _mm512_add_epi64(hl, _mm512_and_si512(mid, mask));           /* < 2^64 */
+    return _mm512_add_epi64(_mm512_add_epi64(hh, _mm512_srli_epi64(mid, 32)), _mm512_srli_epi64(mid2, 32));
+}
+static inline v8 v_shoup(v8 y, v8 w, v8 ws, v8 neg_p) { /* y*w - hi(y*ws)*p  (wrapping) */
+    return _mm512_add_epi64(_mm512_mullo_epi64(y, w), _mm512_mullo_epi64(v_mulhi(y, ws), neg_p));
+}
+typedef struct { v8 p, neg_p, two_p; } vmod;
+static inline void v_fwd_bfly(v8 *z0, v8 *z1, v8 w, v8 ws, const vmod *M, int last) {
+    v8 x = v_small_mod(M->two_p, *z0);
+    if (last) x = v_small_mod(M->p, x);
+    v8 t = v_shoup(*z1, w, ws, M->neg_p);
+    if (last) {
+        t = v_small_mod(M->p, t);
+        *z0 = v_small_mod(M->p, _mm512_add_epi64(x, t));
+        *z1 = v_small_mod(M->p, _mm512_add_epi64(_mm512_sub_epi64(x, t), M->p));
+    } else {
+        *z0 = _mm512_add_epi64(x, t);
+        *z1 = _mm512_add_epi64(_mm512_sub_epi64(x, t), M->two_p);
+    }
+}
+static inline void v_inv_bfly(v8 *z0, v8 *z1, v8 w, v8 ws, const vmod *M, int last) {
+    v8 y0 = v_small_mod(M->two_p, _mm512_add_epi64(*z0, *z1));
+    if (last) y0 = v_small_mod(M->p, y0);
+    v8 t = _mm512_add_epi64(_mm512_sub_epi64(*z0, *z1), M->two_p);
+    v8 y1 = v_shoup(t, w, ws, M->neg_p);
+    if (last) y1 = v_small_mod(M->p, y1);
+    *z0 = y0;
+    *z1 = y1;
+}
+/* in-vector stages: 16 consecutive coefficients (vectors A, B) regrouped so that lane i of Z0 and Z1 form a
+ * butterfly of half-distance T in {4, 2, 1}; W gathers the matching twiddles.  Index tables for vpermt2q. */
+static const long long SPLIT0[3][8] = {{0, 1, 2, 3, 8, 9, 10, 11}, {0, 1, 4, 5, 8, 9, 12, 13}, {0, 2, 4, 6, 8, 10, 12, 14}};
+static const long long SPLIT1[3][8] = {{4, 5, 6, 7, 12, 13, 14, 15}, {2, 3, 6, 7, 10, 11, 14, 15}, {1, 3, 5, 7, 9, 11, 13, 15}};
+static const long long JOIN0[3][8] = {{0, 1, 2, 3, 8, 9, 10, 11}, {0, 1, 8, 9, 2, 3, 10, 11}, {0, 8, 1, 9, 2, 10, 3, 11}};
+static const long long JOIN1[3][8] = {{4, 5, 6, 7, 12, 13, 14, 15}, {4, 5, 12, 13, 6, 7, 14, 15}, {4, 12, 5, 13, 6, 14, 7, 15}};
+static const long long WSEL[3][8] = {{0, 0, 0, 0, 1, 1, 1, 1}, {0, 0, 1, 1, 2, 2, 3, 3}, {0, 1, 2, 3, 4, 5, 6, 7}};
+static inline void v_small_stage(uint64_t *data, size_t n, const uint64_t *w, const uint64_t *ws, int k /*0:T=4,1:T=2,2:T=1*/,
+                                 const vmod *M, int inv, int last) {
+    const v8 s0 = _mm512_loadu_si512(SPLIT0[k]), s1 = _mm512_loadu_si512(SPLIT1[k]);
+    const v8 j0 = _mm512_loadu_si512(JOIN0[k]), j1 = _mm512_loadu_si512(JOIN1[k]);
+    const v8 wsel = _mm512_loadu_si512(WSEL[k]);
+    const size_t wstep = (size_t)2 << k; /* twiddles consumed per 16 coefficients */
+    for (size_t i = 0, wi = 0; i < n; i += 16, wi += wstep) {
+        v8 a = _mm512_loadu_si512(data + i), b = _mm512_loadu_si512(data + i + 8);
+        v8 z0 = _mm512_permutex2var_epi64(a, s0, b), z1 = _mm512_permutex2var_epi64(a, s1, b);
+        /* 8 twiddles are loaded, the first wstep are used (the tables are n long and wi + 8 <= n holds) */
+        v8 wv = _mm512_permutexvar_epi64(wsel, _mm512_loadu_si512(w + wi));
+        v8 wsv = _mm512_permutexvar_epi64(wsel, _mm512_loadu_si512(ws + wi));
+        if (inv)
+            v_inv_bfly(&z0, &z1, wv, wsv, M, last);
+        else
+            v_fwd_bfly(&z0, &z1, wv, wsv, M, last);
+        _mm512_storeu_si512(data + i, _mm512_permutex2var_epi64(z0, j0, z1));
+        _mm512_storeu_si512(data + i + 8, _mm512_permutex2var_epi64(z0, j1, z1));
+    }
+}
+static int avx512_eligible(const orc_plan64 *pl) { return pl->twid_shoup && pl->p < ((uint64_t)1 << 62) && pl->n >= 16; }
+
+void orc_plan64_fwd_avx512(const orc_plan64 *pl, uint64_t *data) {
+    if (!avx512_eligible(pl)) {
+        orc_plan64_fwd(pl, data);
+        return;
+    }
+    const size_t n = pl->n;
+    const vmod M = {_mm512_set1_epi64((long long)pl->p), _mm512_set1_epi64((long long)(0 - pl->p)),
+                    _mm512_set1_epi64((long long)(2 * pl->p))};
+    size_t t = n, m = 1;
+    while (m < n / 8) { /* vector stages: t >= 8 */
+        t /= 2;
+        for (size_t i = 0; i < m; ++i) {
+            const v8 w = _mm512_set1_epi64((long long)pl->twid[m + i]), ws = _mm512_set1_epi64((long long)pl->twid_shoup[m + i]);
+            uint64_t *z0 = data + 2 * i * t, *z1 = z0 + t;
+            for (size_t j = 0; j < t; j += 8) {
+                v8 a = _mm512_loadu_si512(z0 + j), b = _mm512_loadu_si512(z1 + j);
+                v_fwd_bfly(&a, &b, w, ws, &M, 0);
+                _mm512_storeu_si512(z0 + j, a);
+                _mm512_storeu_si512(z1 + j, b);
+            }
+        }
+        m *= 2;
+    }
+    v_small_stage(data, n, pl->twid + n / 8, pl->twid_shoup + n / 8, 0, &M, 0, 0);
+    v_small_stage(data, n, pl->twid + n / 4, pl->twid_shoup + n / 4, 1, &M, 0, 0);
+    v_small_stage(data, n, pl->twid + n / 2, pl->twid_shoup + n / 2, 2, &M, 0, 1);
+}
+void orc_plan64_inv_avx512(const orc_plan64 *pl, uint64_t *data) {
+    if (!avx512_eligible(pl)) {
+        orc_plan64_inv(pl, data);
+        return;
+    }
+    const size_t n = pl->n;
+    const vmod M = {_mm512_set1_epi64((long long)pl->p), _mm512_set1_epi64((long long)(0 - pl->p)),
+                    _mm512_set1_epi64((long long)(2 * pl->p))};
+    v_small_stage(data, n, pl->inv_twid + n / 2, pl->inv_twid_shoup + n / 2, 2, &M, 1, 0);
+    v_small_stage(data, n, pl->inv_twid + n / 4, pl->inv_twid_shoup + n / 4, 1, &M, 1, 0);
+    v_small_stage(data, n, pl->inv_twid + n / 8, pl->inv_twid_shoup + n / 8, 0, &M, 1, 0);
+    size_t t = 8, m = n / 16;
+    while (m >= 1) { /* vector stages: t >= 8 */
+        const int last = m == 1;
+        for (size_t i = 0; i < m; ++i) {
+            const v8 w = _mm512_set1_epi64((long long)pl->inv_twid[m + i]), ws = _mm512_set1_epi64((long long)pl->inv_twid_shoup[m + i]);
+            uint64_t *z0 = data + 2 * i * t, *z1 = z0 + t;
+            for (size_t j = 0; j < t; j += 8) {
+                v8 a = _mm512_loadu_si512(z0 + j), b = _mm512_loadu_si512(z1 + j);
+                v_inv_bfly(&a, &b, w, ws, &M, last);
+                _mm512_storeu_si512(z0 + j, a);
+                _mm512_storeu_si512(z1 + j, b);
+            }
+        }
+        t *= 2;
+        m /= 2;
+    }
+}
+#else
+int orc_avx512_available(void) { return 0; }
+void orc_plan64_fwd_avx512(const orc_plan64 *pl, uint64_t *data) { orc_plan64_fwd(pl, data); }
+void orc_plan64_inv_avx512(const orc_plan64 *pl, uint64_t *data) { orc_plan64_inv(pl, data); }
+#endif
+
+/* ========================================================================= */
 /* schoolbook negacyclic convolution: src/prime64.rs:1143-1182               */
 /* ========================================================================= */
 static inline uint64_t t_add64(uint64_t p, uint64_t a, uint64_t b) {
@@ -1759,6 +1899,14 @@ static void *job_main(void *arg) {
             const orc_plan32 *pl = (const orc_plan32 *)j->plan;
             orc_plan32_inv(pl, (uint32_t *)j->a + i * pl->n);
         } break;
+        case 6: {
+            const orc_plan64 *pl = (const orc_plan64 *)j->plan;
+            orc_plan64_fwd_avx512(pl, (uint64_t *)j->a + i * pl->n);
+        } break;
+        case 7: {
+            const orc_plan64 *pl = (const orc_plan64 *)j->plan;
+            orc_plan64_inv_avx512(pl, (uint64_t *)j->a + i * pl->n);
+        } break;
         case 5: {
             const orc_native *pl = (const orc_native *)j->plan;
             size_t stride = pl->n * (size_t)pl->word;
@@ -1807,6 +1955,58 @@ double orc_plan64_inv_batch(const orc_plan64 *plan, uint64_t *bufs, size_t batch
 double orc_plan64_mul_assign_normalize_batch(const orc_plan64 *plan, uint64_t *lhs, const uint64_t *rhs,
                                              size_t batch, int nthreads) {
     return run_batch(2, plan, lhs, rhs, NULL, batch, nthreads);
+}
+double orc_plan64_fwd_avx512_batch(const orc_plan64 *plan, uint64_t *bufs, size_t batch, int nthreads) {
+    return run_batch(6, plan, bufs, NULL, NULL, batch, nthreads);
+}
+double orc_plan64_inv_avx512_batch(const orc_plan64 *plan, uint64_t *bufs, size_t batch, int nthreads) {
+    return run_batch(7, plan, bufs, NULL, NULL, batch, nthreads);
+}
+/* CPU-baseline driver: every thread runs `reps` x (fwd, inv) over its contiguous share of the batch, so that the
+ * timed region is transform work and not thread start-up (a 1024-point transform takes about a microsecond).
+ * Returns the elapsed seconds; the number of transforms done is 2 * reps * batch. */
+typedef struct {
+    const orc_plan64 *plan;
+    uint64_t *bufs;
+    size_t lo, hi;
+    int reps, avx512;
+} loop_job_t;
+static void *loop_job_main(void *arg) {
+    const loop_job_t *j = (const loop_job_t *)arg;
+    const size_t n = j->plan->n;
+    for (int r = 0; r < j->reps; ++r)
+        for (size_t i = j->lo; i < j->hi; ++i) {
+            uint64_t *b = j->bufs + i * n;
+            if (j->avx512) {
+                orc_plan64_fwd_avx512(j->plan, b);
+                orc_plan64_inv_avx512(j->plan, b);
+            } else {
+                orc_plan64_fwd(j->plan, b);
+                orc_plan64_inv(j->plan, b);
+            }
+        }
+    return NULL;
+}
+double orc_plan64_fwd_inv_loop(const orc_plan64 *plan, uint64_t *bufs, size_t batch, int nthreads, int reps, int avx512) {
+    if (nthreads < 1) nthreads = 1;
+    if ((size_t)nthreads > batch) nthreads = batch ? (int)batch : 1;
+    loop_job_t *jobs = (loop_job_t *)calloc((size_t)nthreads, sizeof(loop_job_t));
+    pthread_t *th = (pthread_t *)calloc((size_t)nthreads, sizeof(pthread_t));
+    double t0 = now_s();
+    for (int t = 0; t < nthreads; ++t) {
+        jobs[t] = (loop_job_t){plan, bufs, batch * (size_t)t / (size_t)nthreads, batch * (size_t)(t + 1) / (size_t)nthreads,
+                               reps, avx512};
+        if (nthreads == 1)
+            loop_job_main(&jobs[t]);
+        else
+            pthread_create(&th[t], NULL, loop_job_main, &jobs[t]);
+    }
+    if (nthreads > 1)
+        for (int t = 0; t < nthreads; ++t) pthread_join(th[t], NULL);
+    double t1 = now_s();
+    free(jobs);
+    free(th);
+    return t1 - t0;
 }
 double orc_plan32_fwd_batch(const orc_plan32 *plan, uint32_t *bufs, size_t batch, int nthreads) {
     return run_batch(3, plan, bufs, NULL, NULL, batch, nthreads);

@@ -64,6 +64,12 @@ void orc_plan64_normalize(const orc_plan64 *plan, uint64_t *values, size_t len);
 void orc_plan64_mul_accumulate(const orc_plan64 *plan, uint64_t *acc, const uint64_t *lhs,
                                const uint64_t *rhs, size_t len);                 /* :1085-1128 */
 
+/* AVX-512 restatement of the 62-bit-class transforms (src/prime64/shoup.rs:10-156, :712-870): present in builds that
+ * target AVX-512F+DQ (make native on such a host), scalar otherwise; CPU-baseline use only. */
+int orc_avx512_available(void);
+void orc_plan64_fwd_avx512(const orc_plan64 *plan, uint64_t *buf);
+void orc_plan64_inv_avx512(const orc_plan64 *plan, uint64_t *buf);
+
 /* ---- prime32::Plan (src/prime32.rs:601-616) ---- */
 typedef struct orc_plan32 {
     size_t n;
@@ -185,6 +191,9 @@ double orc_plan64_fwd_batch(const orc_plan64 *plan, uint64_t *bufs, size_t batch
 double orc_plan64_inv_batch(const orc_plan64 *plan, uint64_t *bufs, size_t batch, int nthreads);
 double orc_plan64_mul_assign_normalize_batch(const orc_plan64 *plan, uint64_t *lhs,
                                              const uint64_t *rhs, size_t batch, int nthreads);
+double orc_plan64_fwd_avx512_batch(const orc_plan64 *plan, uint64_t *bufs, size_t batch, int nthreads);
+double orc_plan64_inv_avx512_batch(const orc_plan64 *plan, uint64_t *bufs, size_t batch, int nthreads);
+double orc_plan64_fwd_inv_loop(const orc_plan64 *plan, uint64_t *bufs, size_t batch, int nthreads, int reps, int avx512);
 double orc_plan32_fwd_batch(const orc_plan32 *plan, uint32_t *bufs, size_t batch, int nthreads);
 double orc_plan32_inv_batch(const orc_plan32 *plan, uint32_t *bufs, size_t batch, int nthreads);
 double orc_native_negacyclic_polymul_batch(const orc_native *plan, void *prod, const void *lhs,

@@ -101,6 +101,12 @@ def lib(native=False):
         "orc_plan64_fwd_batch": (c_dbl, [c_vp, c_vp, c_sz, c_int]),
         "orc_plan64_inv_batch": (c_dbl, [c_vp, c_vp, c_sz, c_int]),
         "orc_plan64_mul_assign_normalize_batch": (c_dbl, [c_vp, c_vp, c_vp, c_sz, c_int]),
+        "orc_avx512_available": (c_int, []),
+        "orc_plan64_fwd_avx512": (None, [c_vp, c_vp]),
+        "orc_plan64_inv_avx512": (None, [c_vp, c_vp]),
+        "orc_plan64_fwd_avx512_batch": (c_dbl, [c_vp, c_vp, c_sz, c_int]),
+        "orc_plan64_inv_avx512_batch": (c_dbl, [c_vp, c_vp, c_sz, c_int]),
+        "orc_plan64_fwd_inv_loop": (c_dbl, [c_vp, c_vp, c_sz, c_int, c_int, c_int]),
         "orc_plan32_fwd_batch": (c_dbl, [c_vp, c_vp, c_sz, c_int]),
         "orc_plan32_inv_batch": (c_dbl, [c_vp, c_vp, c_sz, c_int]),
         "orc_native_negacyclic_polymul_batch": (c_dbl, [c_vp, c_vp, c_vp, c_vp, c_sz, c_int]),
@@ -176,6 +182,28 @@ class Plan:
 
     def mul_accumulate(self, acc, lhs, rhs):
         self._f("mul_accumulate")(self._h, _ptr(acc), _ptr(lhs), _ptr(rhs), min(acc.size, lhs.size, rhs.size))
+
+    def avx512_available(self):
+        """True when this build carries the AVX-512 restatement (62-bit class, u64) and the CPU runs it."""
+        return self.bits == 64 and bool(self._L.orc_avx512_available())
+
+    def fwd_avx512(self, buf):
+        assert self.bits == 64 and buf.dtype == np.uint64 and buf.size == self.n
+        self._L.orc_plan64_fwd_avx512(self._h, _ptr(buf))
+
+    def inv_avx512(self, buf):
+        assert self.bits == 64 and buf.dtype == np.uint64 and buf.size == self.n
+        self._L.orc_plan64_inv_avx512(self._h, _ptr(buf))
+
+    def fwd_avx512_batch(self, bufs, nthreads=1):
+        return self._L.orc_plan64_fwd_avx512_batch(self._h, _ptr(bufs), bufs.size // self.n, nthreads)
+
+    def inv_avx512_batch(self, bufs, nthreads=1):
+        return self._L.orc_plan64_inv_avx512_batch(self._h, _ptr(bufs), bufs.size // self.n, nthreads)
+
+    def fwd_inv_loop(self, bufs, nthreads=1, reps=1, avx512=False):
+        """seconds for `reps` x (fwd, inv) of every polynomial in bufs, split over nthreads (CPU-baseline driver)."""
+        return self._L.orc_plan64_fwd_inv_loop(self._h, _ptr(bufs), bufs.size // self.n, nthreads, reps, 1 if avx512 else 0)
 
     def fwd_batch(self, bufs, nthreads=1):
         assert bufs.dtype == self.dtype and bufs.size % self.n == 0

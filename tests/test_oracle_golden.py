@@ -217,3 +217,25 @@ def test_prime_search(oracle, golden):
         out = ctypes.c_uint64(0)
         assert L.orc_largest_prime_in_arithmetic_progression64(*args, ctypes.addressof(out))
         assert out.value == val
+
+
+def test_avx512_restatement_equals_scalar_engine(oracle):
+    """oracle's AVX-512 restatement of the 62-bit-class engine (src/prime64/shoup.rs:10-156, used for the CPU
+    baseline on AVX-512 hosts) against its scalar engine: same words for every size, both directions."""
+    import subprocess
+    if "avx512dq" not in open("/proc/cpuinfo").read():
+        pytest.skip("host CPU has no AVX-512F+DQ")
+    oracle.build(native=True)
+    for p, sizes in ((4611686018427322369, (16, 32, 64, 128, 1024, 2048, 8192)), (1125899904679937, (16, 512)),
+                     (9223372036853661697, (64,))):   # the last one is the 63-bit class: falls back to scalar
+        for n in sizes:
+            plan = oracle.Plan.try_new(n, p, 64, native=True)
+            assert plan.avx512_available()
+            a = oracle.fill_uniform(n, p, 3 * n + 1, 64)
+            x, y = a.copy(), a.copy()
+            plan.fwd(x)
+            plan.fwd_avx512(y)
+            assert np.array_equal(x, y), ("fwd", n, p)
+            plan.inv(x)
+            plan.inv_avx512(y)
+            assert np.array_equal(x, y), ("inv", n, p)
