@@ -525,3 +525,19 @@ def test_batch_calls_capture_into_a_hip_graph(oracle):
     prod0 = np.zeros(n, dtype=np.uint64)
     onat.negacyclic_polymul(prod0, lhs[:n].copy(), rhs[:n].copy())
     assert np.array_equal(ref_native[:n], prod0)
+
+
+@pytest.mark.parametrize("bits,logn,p", [
+    (64, 17, 4611686018425815041),      # lazy class, depth-3 global stages (62-bit prime = 1 mod 2^18)
+    (64, 18, 18446744069414584321),     # Solinas (generic class), depth 4
+    (64, 17, 9223372036836950017),      # strict class: largest 63-bit prime = 1 mod 2^18
+    (32, 17, 2013265921),               # 15 * 2^27 + 1 (31-bit class), depth 2
+    (32, 18, 4293918721),               # generic u32 (2^32 - 2^20 + 1), depth 3
+])
+def test_very_large_transforms_vs_oracle(oracle, plans, oplans, bits, logn, p):
+    """N = 2^17, 2^18: several global stages in front of / behind the LDS-resident sub-transforms
+    (the reference's depth-first recursion, src/prime64/shoup.rs:660-682), every arithmetic class."""
+    n = 1 << logn
+    if oracle.Plan.try_new(n, p, bits) is None:
+        pytest.skip("%d is not an NTT prime for n = 2^%d" % (p, logn))
+    _batch_case(oracle, plans, oplans, bits, n, p, 3, 7000 + logn)
