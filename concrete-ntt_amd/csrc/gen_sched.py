@@ -122,8 +122,12 @@ def default_swz(bits, logn, loge, passes):
     return terms
 
 
-def make_sched(bits, logn, inv):
+def make_sched(bits, logn, inv, fam=0):
+    """fam 0: the tuned schedule; fam 1: the 16-coefficients-per-thread schedule where fam 0 overrides LOGE
+    (the whole-polymul kernels keep K residue tiles in registers and cannot afford 32 per thread)."""
     ov = OVERRIDES.get((bits, logn, inv), {})
+    if fam == 1:
+        ov = {k: v for k, v in ov.items() if k != "loge"}
     loge = ov.get("loge", default_loge(bits, logn))
     passes = ov.get("passes") or make_passes(bits, logn, inv, loge, ov.get("first_x"))
     swz = ov.get("swz", default_swz(bits, logn, loge, passes))
@@ -268,16 +272,24 @@ def report(s):
 # --------------------------------------------------------------------------------------------
 def emit(path):
     lines = ["// GENERATED by gen_sched.py -- do not edit; re-run `python3 gen_sched.py`.",
-             "// Sched<BITS, LOGN, INV>: pass masks and LDS swizzle of the LDS-resident NTT kernels.", ""]
+             "// Sched<BITS, LOGN, INV, FAM>: pass masks and LDS swizzle of the LDS-resident NTT kernels.",
+             "// FAM 1 = 16 coefficients per thread wherever FAM 0 uses 32 (falls back to FAM 0 elsewhere).", ""]
+    keys = []
     for bits in (64, 32):
         for logn in range(4, 16):
             if not supported(bits, logn):
                 continue
             for inv in (False, True):
-                s = make_sched(bits, logn, inv)
+                keys.append((bits, logn, inv, 0))
+                if "loge" in OVERRIDES.get((bits, logn, inv), {}):
+                    keys.append((bits, logn, inv, 1))
+    for bits, logn, inv, fam in keys:
+            if True:
+                s = make_sched(bits, logn, inv, fam)
                 np_ = len(s.passes)
                 swz = list(s.swz) + [(0, 0, 0)] * (2 - len(s.swz))
-                lines.append("template <> struct Sched<%d, %d, %s> {" % (bits, logn, "true" if inv else "false"))
+                lines.append("template <> struct Sched<%d, %d, %s%s> {" % (bits, logn, "true" if inv else "false",
+                                                                         ", 1" if fam else ""))
                 lines.append("    static constexpr int LOGE = %d, NPASS = %d, BLOCK = %d;" % (s.loge, np_, s.block))
                 lines.append("    static constexpr uint32_t RMASK[%d] = {%s};" %
                              (np_, ", ".join("0x%xu" % r for r, _ in s.passes)))
@@ -304,14 +316,16 @@ def check():
                 pass
             pl = gg.Plan(n, p, bits)
             a = [rnd.randrange(p) for _ in range(n)]
-            for inv in (False, True):
-                s = make_sched(bits, logn, inv)
+            for inv, fam in ((False, 0), (True, 0), (False, 1), (True, 1)):
+                if fam == 1 and "loge" not in OVERRIDES.get((bits, logn, inv), {}):
+                    continue
+                s = make_sched(bits, logn, inv, fam)
                 table = pl.inv_twid if inv else pl.twid
                 got = replay(s, a, p, table)
                 want = direct(logn, inv, a, p, table)
-                assert got == want, (bits, logn, inv)
-                print("ok bits=%d logn=%2d inv=%d loge=%d tpp=%4d block=%4d passes=%s lds(w,r)=%s" % (
-                    bits, logn, inv, s.loge, s.tpp, s.block,
+                assert got == want, (bits, logn, inv, fam)
+                print("ok bits=%d logn=%2d inv=%d fam=%d loge=%d tpp=%4d block=%4d passes=%s lds(w,r)=%s" % (
+                    bits, logn, inv, fam, s.loge, s.tpp, s.block,
                     ["%x/%x" % (r, g) for r, g in s.passes],
                     ["%.1f/%.1f" % wr for wr in report(s)]))
 

@@ -17,6 +17,7 @@
 #include "../../include/cntt.h"
 #include "aux_kernels.hpp"
 #include "host_math.hpp"
+#include "native_fused.hpp"
 #include "ntt_launch.hpp"
 
 using namespace cntt;
@@ -708,13 +709,12 @@ template <class W, class R> static void launch_split(const void *value, const Sp
 struct W128 {
     uint64_t lo, hi;
 };
-static int native_split_device(const cntt_native *pl, const void *value, void *const *res, size_t count, bool binary,
-                               hipStream_t st) {
+static SplitArgs native_split_args(const cntt_native *pl, void *const *res) {
     SplitArgs A{};
     A.k = pl->info.nprimes;
     for (int i = 0; i < A.k; ++i) {
         const uint64_t p = pl->prime(i);
-        A.res[i] = res[i];
+        A.res[i] = res ? res[i] : nullptr;
         A.prime[i] = p;
         if (pl->info.is52) {
             A.barrett[i] = (uint64_t)((((u128)1) << 64) / p);
@@ -725,6 +725,11 @@ static int native_split_device(const cntt_native *pl, const void *value, void *c
             A.one_shoup[i] = (uint32_t)((((uint64_t)1) << 32) / p);
         }
     }
+    return A;
+}
+static int native_split_device(const cntt_native *pl, const void *value, void *const *res, size_t count, bool binary,
+                               hipStream_t st) {
+    const SplitArgs A = native_split_args(pl, res);
     // a u32 word is always below the 50-bit primes: src/native32.rs:447-452 copies it without `%`
     if (pl->info.is52) {
         if (pl->info.word == 4)
@@ -873,8 +878,43 @@ extern "C" int cntt_native_reserve(const cntt_native_t *pl, size_t batch) {
 }
 
 // negacyclic_polymul on device memory: src/native64.rs:1042-1069 batched
+// whole product in one kernel (native_fused.hpp) for the Plan32 kinds with 32/64-bit words, 32 <= n <= 4096
+template <int KIND>
+static hipError_t native_fused_try(const cntt_native *pl, void *prod, const void *lhs, const void *rhs, size_t batch,
+                                   hipStream_t st, int *rc_out) {
+    constexpr int KP = NativeShape<KIND>::KP;
+    FusedTables<KP> F{};
+    for (int i = 0; i < KP; ++i) {
+        DeviceTables<uint32_t> t;
+        if (int rc = device_tables(pl->p32[(size_t)i].get(), &t)) {
+            *rc_out = rc;
+            return hipErrorUnknown;
+        }
+        F.twf[i] = t.fwd;
+        F.twi[i] = t.inv;
+        F.P[i] = pl->p32[(size_t)i]->mp;
+    }
+    const SplitArgs S = native_split_args(pl, nullptr);
+    return launch_native_fused<KIND>(pl->p32[0]->logn, prod, lhs, rhs, &F, S, pl->crt, (uint32_t)batch, st);
+}
+
 static int native_polymul_device(const cntt_native *pl, void *prod, const void *lhs, const void *rhs, size_t batch,
                                  hipStream_t st) {
+    if (batch > 0 && batch < ((size_t)1 << 32) && !pl->info.is52 && pl->info.word <= 8) {
+        int rc = CNTT_OK;
+        hipError_t e = hipErrorNotSupported;
+        switch (pl->kind) {
+        case CNTT_NATIVE32_PLAN32: e = native_fused_try<0>(pl, prod, lhs, rhs, batch, st, &rc); break;
+        case CNTT_NATIVE64_PLAN32: e = native_fused_try<1>(pl, prod, lhs, rhs, batch, st, &rc); break;
+        case CNTT_NATIVE_BINARY32_PLAN32: e = native_fused_try<3>(pl, prod, lhs, rhs, batch, st, &rc); break;
+        case CNTT_NATIVE_BINARY64_PLAN32: e = native_fused_try<4>(pl, prod, lhs, rhs, batch, st, &rc); break;
+        default: break;
+        }
+        if (rc != CNTT_OK) return rc;
+        if (e == hipSuccess) return CNTT_OK;
+        if (e != hipErrorNotSupported) return fail(CNTT_EDEVICE, "fused polymul launch failed: %s", hipGetErrorString(e));
+        (void)hipGetLastError();
+    }
     void *base = nullptr;
     if (int rc = native_workspace(pl, batch, &base)) return rc;
     const int k = pl->info.nprimes;

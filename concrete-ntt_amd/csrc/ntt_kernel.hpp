@@ -15,8 +15,11 @@
 
 namespace cntt {
 
-template <int BITS, int LOGN, bool INV> struct Sched;  // specialisations: sched_gen.inc
+// FAM 0: the tuned schedule.  FAM 1: 16 coefficients per thread wherever FAM 0 uses 32 (u32 N=2048/4096) -- for
+// kernels that keep several residue tiles in registers; identical to FAM 0 for every other size.
+template <int BITS, int LOGN, bool INV, int FAM = 0> struct Sched;  // specialisations: sched_gen.inc
 #include "sched_gen.inc"
+template <int BITS, int LOGN, bool INV> struct Sched<BITS, LOGN, INV, 1> : Sched<BITS, LOGN, INV, 0> {};
 
 // ---- compile-time bit helpers ---------------------------------------------------------------
 __host__ __device__ constexpr int cpop(uint32_t m) {
@@ -91,11 +94,11 @@ struct LabStamp {
 // ---- the kernel -----------------------------------------------------------------------------
 // LAB: ablation flags for tools/ntt_lab.hip only (product instantiations use 0):
 //   1 = no per-thread twiddle loads, 2 = no LDS exchange, 4 = no global load/store, 8 = stamp clocks
-template <class T, int LOGN, bool INV, int CLS, bool SUB, int LAB = 0>
+template <class T, int LOGN, bool INV, int CLS, bool SUB, int LAB = 0, int FAM = 0>
 struct NttKernel {
     using elem_t = T;
     static constexpr int BITS = sizeof(T) * 8;
-    using S = Sched<BITS, LOGN, INV>;
+    using S = Sched<BITS, LOGN, INV, FAM>;
     static constexpr int LOGE = S::LOGE, E = 1 << LOGE, NPASS = S::NPASS, BLOCK = S::BLOCK;
     static constexpr int TPP = 1 << (LOGN - LOGE);
     static constexpr int PPB = (BLOCK / TPP) > 0 ? (BLOCK / TPP) : 1;
@@ -399,9 +402,9 @@ struct NttKernel {
 // vector-memory wait sits inside the compute phase (twiddles come from LDS / scalar loads), so HBM
 // streaming overlaps the VALU-bound passes instead of alternating with them.
 // -------------------------------------------------------------------------------------------------
-template <class T, int LOGN, bool INV, int CLS, int WPB, bool STAMP = false>
-struct NttWp : NttKernel<T, LOGN, INV, CLS, false, 0> {
-    using B = NttKernel<T, LOGN, INV, CLS, false, 0>;
+template <class T, int LOGN, bool INV, int CLS, int WPB, bool STAMP = false, int FAM = 0>
+struct NttWp : NttKernel<T, LOGN, INV, CLS, false, 0, FAM> {
+    using B = NttKernel<T, LOGN, INV, CLS, false, 0, FAM>;
     using S = typename B::S;
     static constexpr int E = B::E, TPP = B::TPP, NPASS = B::NPASS;
     static constexpr int BLOCK = WPB, PPB = WPB / TPP;
@@ -421,18 +424,20 @@ struct NttWp : NttKernel<T, LOGN, INV, CLS, false, 0> {
         }
     }
 
-    template <int K, bool NORM = false>
+    // IMG: thread-dependent twiddles come from the workgroup's LDS image (fill_image); otherwise from the table in
+    // global memory (L2), for kernels that walk several primes and cannot hold an image per prime
+    template <int K, bool NORM = false, bool IMG = true>
     static __device__ __forceinline__ void pass(T (&r)[E], T *lds, uint32_t tid, const TwPair<T> *__restrict__ tw,
                                                 const TwPair<T> *img, const ModParams<T> &P) {
         constexpr uint32_t RM = S::RMASK[K], CM = FULL & ~RM;
         const uint32_t ebase = pdep<CM>(tid);
         if constexpr (K > 0) B::template gather<RM>(r, (const T *)lds, ebase, true);
-        B::template stages<K, 0, true, NORM>(r, ebase, 0u, 0u, tw, P, tid, img);
+        B::template stages<K, 0, IMG, NORM>(r, ebase, 0u, 0u, tw, P, tid, img);
         if constexpr (K < NPASS - 1) {
             if constexpr (K > 0) wsync();
             B::template scatter<RM>(r, lds, ebase, true);
             wsync();
-            pass<K + 1, NORM>(r, lds, tid, tw, img, P);
+            pass<K + 1, NORM, IMG>(r, lds, tid, tw, img, P);
         } else {
 #pragma unroll
             for (int j = 0; j < E; ++j) r[j] = INV ? Bfly<T, CLS>::finish_inv(r[j], P) : Bfly<T, CLS>::finish_fwd(r[j], P);

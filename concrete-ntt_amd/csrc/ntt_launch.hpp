@@ -50,4 +50,12 @@ inline hipError_t launch_ext_ntt(int logn, int cls, T *out, const T *terms, cons
     }
 }
 
+// Whole negacyclic_polymul of one native Plan32 kind (native_fused.hpp) for 32 <= n <= 4096; hipErrorNotSupported
+// otherwise.  `tables` points to the FusedTables<KP> of the plan (native_fused.hpp); KIND = cntt_native_kind_t value.
+struct SplitArgs;
+struct CrtArgs;
+template <int KIND>
+hipError_t launch_native_fused(int logn, void *prod, const void *lhs, const void *rhs, const void *tables, const SplitArgs &S,
+                               const CrtArgs &C, uint32_t batch, hipStream_t st);
+
 }  // namespace cntt
