@@ -98,19 +98,18 @@ template <class SH> __device__ __forceinline__ typename SH::W crt_regs(const uin
             const uint32_t d = (uint32_t)rg[g] - acc + m;
             v[g] = shoup_mulmod32(d, (uint32_t)A.inv[g], A.inv_shoup32[g], m);
         } else {
+            // the digit moduli of these plans ascend (P0 < P1 P2 < P3 P4), so every digit v[h] < M[h] < M[g] and the
+            // group residue rg[g] < M[g] are already canonical modulo M[g]: no reduction (crt_kernel keeps a guarded
+            // `%` there; a 64-bit `%` expands to a long division routine, ruinous next to five live residue tiles)
             const uint64_t m = A.M[g];
             uint64_t acc = v[g - 1];
-            if (acc >= m) acc %= m;
 #pragma unroll
             for (int h = g - 2; h >= 0; --h) {
                 uint64_t t = shoup_mulmod(acc, A.Mmod[g][h], A.Mmod_shoup[g][h], m);
-                uint64_t vh = v[h];
-                if (vh >= m) vh %= m;
-                t += vh;
+                t += v[h];
                 acc = t >= m ? t - m : t;
             }
-            uint64_t rr = rg[g];
-            if (rr >= m) rr %= m;
+            const uint64_t rr = rg[g];
             const uint64_t d = rr >= acc ? rr - acc : rr + m - acc;
             v[g] = shoup_mulmod(d, A.inv[g], A.inv_shoup[g], m);
         }
@@ -149,13 +148,14 @@ __global__ __launch_bounds__(BLK, 2) void native_polymul_kernel(typename NativeS
         constexpr int i = ic.value;
         uint32_t a[E], b[E];
 #pragma unroll
-        for (int j = 0; j < E; ++j) {
-            const uint32_t e = ebase | cdep((uint32_t)j, RM0);
-            a[j] = split30<W>(lp[e], S, i);
-            b[j] = SH::BINARY ? (uint32_t)rp[e] : split30<W>(rp[e], S, i);  // `as u32`: src/native_binary64.rs:379-385
-        }
+        for (int j = 0; j < E; ++j) a[j] = split30<W>(lp[ebase | cdep((uint32_t)j, RM0)], S, i);
         Wf::template pass<0, false, false>(a, lds, tid, F.twf[i], nullptr, F.P[i]);
         Wf::wsync();
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            const W w = rp[ebase | cdep((uint32_t)j, RM0)];
+            b[j] = SH::BINARY ? (uint32_t)w : split30<W>(w, S, i);  // `as u32`: src/native_binary64.rs:379-385
+        }
         Wf::template pass<0, false, false>(b, lds, tid, F.twf[i], nullptr, F.P[i]);
 #pragma unroll
         for (int j = 0; j < E; ++j) a[j] = mul_for_inv<uint32_t, CLS_LAZY>(a[j], b[j], F.P[i]);
