@@ -307,19 +307,18 @@ __global__ __launch_bounds__(256) void crt_kernel(W *__restrict__ value, CrtArgs
                 const uint32_t d = rr - acc + m;  // in (0, 2m)
                 v[g] = shoup_mulmod32(d, (uint32_t)A.inv[g], A.inv_shoup32[g], m);
             } else {
+                // The digit moduli of every reference plan ascend (host.hip build_crt_args checks it), so each digit
+                // v[h] < M[h] < M[g] and the group residue rg[g] < M[g] are canonical modulo M[g] as they are.  (A guarded
+                // 64-bit `%` here expands to a long-division routine even though it never runs.)
                 const uint64_t m = A.M[g];
                 uint64_t acc = v[g - 1];
-                if (acc >= m) acc %= m;  // never taken for the reference's ascending moduli; kept for safety
 #pragma unroll
                 for (int h = g - 2; h >= 0; --h) {
                     uint64_t t = shoup_mulmod(acc, A.Mmod[g][h], A.Mmod_shoup[g][h], m);
-                    uint64_t vh = v[h];
-                    if (vh >= m) vh %= m;
-                    t += vh;
+                    t += v[h];
                     acc = t >= m ? t - m : t;
                 }
-                uint64_t rr = rg[g];
-                if (rr >= m) rr %= m;
+                const uint64_t rr = rg[g];
                 const uint64_t d = rr >= acc ? rr - acc : rr + m - acc;
                 v[g] = shoup_mulmod(d, A.inv[g], A.inv_shoup[g], m);
             }

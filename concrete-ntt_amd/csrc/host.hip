@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -631,6 +632,9 @@ static void build_crt_args(cntt_native *pl) {
         }
         M[(size_t)g] = m;
         A.M[g] = m;
+        // the CRT kernels rely on ascending digit moduli (digits and group residues need no reduction modulo a later
+        // modulus); true for every reference plan: primes ascend within primes32 / primes52 (src/lib.rs:447-652)
+        if (g > 0 && !(M[(size_t)g - 1] < m)) std::abort();
         A.prefix_lo[g] = (uint64_t)prefix;
         A.prefix_hi[g] = (uint64_t)(prefix >> 64);
         if (g > 0) {
