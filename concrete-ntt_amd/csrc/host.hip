@@ -19,6 +19,7 @@
 #include "aux_kernels.hpp"
 #include "host_math.hpp"
 #include "native_fused.hpp"
+#include "product_fused.hpp"
 #include "ntt_launch.hpp"
 
 using namespace cntt;
@@ -1102,11 +1103,41 @@ static int product_split_device(const cntt_product *pl, ProductView v, const uin
     return CNTT_OK;
 }
 
+// u32x2 plans whose primes share an arithmetic class: split + both forward transforms, or both inverse transforms +
+// Garner, in one kernel (product_fused.hpp).  Returns hipErrorNotSupported when the plan / size is not covered.
+static hipError_t product_fused2_try(const cntt_product *pl, bool inv, uint64_t *standard, uint32_t *res32, size_t batch,
+                                     bool flag, hipStream_t st, int *rc_out) {
+    if (pl->p32.size() != 2 || !pl->p64.empty() || batch == 0 || batch >= ((size_t)1 << 32)) return hipErrorNotSupported;
+    const cntt_plan32 *q0 = pl->p32[0].get(), *q1 = pl->p32[1].get();
+    if (q0->mp.cls != q1->mp.cls) return hipErrorNotSupported;
+    ProductFusedTables F{};
+    for (int i = 0; i < 2; ++i) {
+        DeviceTables<uint32_t> t;
+        if (int rc = device_tables(pl->p32[(size_t)i].get(), &t)) {
+            *rc_out = rc;
+            return hipErrorUnknown;
+        }
+        F.twf[i] = t.fwd;
+        F.twi[i] = t.inv;
+        F.P[i] = pl->p32[(size_t)i]->mp;
+    }
+    return launch_product_fused2(q0->logn, (int)q0->mp.cls, inv, standard, res32, &F, pl->args, (uint32_t)batch, flag, st);
+}
+
 // Plan::fwd src/product.rs:273-357  (device pointers)
 static int product_fwd_device(const cntt_product *pl, uint64_t *ntt, const uint64_t *standard, size_t batch,
                               bool bounded, uint64_t bound, hipStream_t st) {
     if (batch == 0 || pl->primes.empty()) return CNTT_OK;
     const ProductView v = product_view(pl, ntt, batch);
+    {
+        int rc = CNTT_OK;
+        const bool fast = bounded && pl->p32.size() == 2 && bound < pl->args.prime[0] && bound < pl->args.prime[1];
+        const hipError_t e = product_fused2_try(pl, false, const_cast<uint64_t *>(standard), v.r32, batch, fast, st, &rc);
+        if (rc != CNTT_OK) return rc;
+        if (e == hipSuccess) return CNTT_OK;
+        if (e != hipErrorNotSupported) return fail(CNTT_EDEVICE, "fused product forward launch failed: %s", hipGetErrorString(e));
+        (void)hipGetLastError();
+    }
     if (int rc = product_split_device(pl, v, standard, batch, bounded, bound, st)) return rc;
     return product_ntt_device(pl, v, batch, false, st);
 }
@@ -1149,6 +1180,14 @@ static int product_inv_device(const cntt_product *pl, uint64_t *standard, uint64
         return CNTT_OK;
     }
     const ProductView v = product_view(pl, ntt, batch);
+    {
+        int rc = CNTT_OK;
+        const hipError_t e = product_fused2_try(pl, true, standard, v.r32, batch, accumulate, st, &rc);
+        if (rc != CNTT_OK) return rc;
+        if (e == hipSuccess) return CNTT_OK;
+        if (e != hipErrorNotSupported) return fail(CNTT_EDEVICE, "fused product inverse launch failed: %s", hipGetErrorString(e));
+        (void)hipGetLastError();
+    }
     if (int rc = product_ntt_device(pl, v, batch, true, st)) return rc;
     return product_crt_device(pl, standard, v, batch, accumulate, st);
 }

@@ -54,6 +54,12 @@ inline hipError_t launch_ext_ntt(int logn, int cls, T *out, const T *terms, cons
 // otherwise.  `tables` points to the FusedTables<KP> of the plan (native_fused.hpp); KIND = cntt_native_kind_t value.
 struct SplitArgs;
 struct CrtArgs;
+struct ProductArgs;
+// product::Plan with two u32 primes of one arithmetic class `cls`, 32 <= n <= 4096 (product_fused.hpp): forward
+// (flag = FwdMode::Bounded applies) or inverse (flag = InvMode::Accumulate) in one kernel; `tables` points to a
+// ProductFusedTables.  hipErrorNotSupported for other sizes.
+hipError_t launch_product_fused2(int logn, int cls, bool inv, uint64_t *standard, uint32_t *res32, const void *tables,
+                                 const ProductArgs &A, uint32_t batch, bool flag, hipStream_t st);
 template <int KIND>
 hipError_t launch_native_fused(int logn, void *prod, const void *lhs, const void *rhs, const void *tables, const SplitArgs &S,
                                const CrtArgs &C, uint32_t batch, hipStream_t st);
