@@ -22,11 +22,7 @@ __global__ __launch_bounds__(256) void pointwise_kernel(T *__restrict__ a, const
     const bool generic = P.cls == CLS_GENERIC;
     const size_t nvec = count / NV;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
-        V va = reinterpret_cast<const V *>(a)[i];
-        V vb, vc;
-        if constexpr (OP != PW_NORMALIZE) vb = reinterpret_cast<const V *>(b)[i];
-        if constexpr (OP == PW_MUL_ACCUMULATE) vc = reinterpret_cast<const V *>(c)[i];
+    auto apply = [&](V &va, const V &vb, const V &vc) {
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
             if constexpr (OP == PW_MUL_NORMALIZE) va[k] = mul_normalize<T>(va[k], vb[k], P, generic);
@@ -34,6 +30,31 @@ __global__ __launch_bounds__(256) void pointwise_kernel(T *__restrict__ a, const
             if constexpr (OP == PW_MUL_ACCUMULATE) va[k] = mul_acc<T>(va[k], vb[k], vc[k], P, generic);
             if constexpr (OP == PW_ADD) va[k] = add_mod<T>(va[k], vb[k], P.p);
         }
+    };
+    // two vectors per thread in flight (the loads of the second are issued before the arithmetic of the first)
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + stride < nvec; i += 2 * stride) {
+        V va0 = reinterpret_cast<const V *>(a)[i], va1 = reinterpret_cast<const V *>(a)[i + stride];
+        V vb0 = va0, vb1 = va1, vc0 = va0, vc1 = va1;
+        if constexpr (OP != PW_NORMALIZE) {
+            vb0 = reinterpret_cast<const V *>(b)[i];
+            vb1 = reinterpret_cast<const V *>(b)[i + stride];
+        }
+        if constexpr (OP == PW_MUL_ACCUMULATE) {
+            vc0 = reinterpret_cast<const V *>(c)[i];
+            vc1 = reinterpret_cast<const V *>(c)[i + stride];
+        }
+        apply(va0, vb0, vc0);
+        apply(va1, vb1, vc1);
+        reinterpret_cast<V *>(a)[i] = va0;
+        reinterpret_cast<V *>(a)[i + stride] = va1;
+    }
+    for (; i < nvec; i += stride) {
+        V va = reinterpret_cast<const V *>(a)[i];
+        V vb = va, vc = va;
+        if constexpr (OP != PW_NORMALIZE) vb = reinterpret_cast<const V *>(b)[i];
+        if constexpr (OP == PW_MUL_ACCUMULATE) vc = reinterpret_cast<const V *>(c)[i];
+        apply(va, vb, vc);
         reinterpret_cast<V *>(a)[i] = va;
     }
     // tail (count not a multiple of the vector width)
