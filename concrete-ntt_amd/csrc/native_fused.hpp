@@ -122,7 +122,9 @@ template <class SH> __device__ __forceinline__ typename SH::W crt_regs(const uin
     return (typename SH::W)out;
 }
 
-template <int KIND, int LOGN, int BLK>
+// PARK: the first PARK finished residue tiles wait for the CRT in LDS (thread-private slots, no synchronisation)
+// instead of registers -- five tiles of a 4096-point product do not fit the 256 VGPRs of two waves per SIMD.
+template <int KIND, int LOGN, int BLK, int PARK = 0>
 __global__ __launch_bounds__(BLK, 2) void native_polymul_kernel(typename NativeShape<KIND>::W *__restrict__ prod,
                                                              const typename NativeShape<KIND>::W *__restrict__ lhs,
                                                              const typename NativeShape<KIND>::W *__restrict__ rhs,
@@ -137,13 +139,14 @@ __global__ __launch_bounds__(BLK, 2) void native_polymul_kernel(typename NativeS
     static_assert(RM0 == Wi::S::RMASK[NPASS - 1] && Wf::S::RMASK[NPASS - 1] == Wi::S::RMASK[0],
                   "forward and inverse schedules must mirror each other");
     __shared__ __attribute__((aligned(16))) uint32_t lds_all[(size_t)PPB << LOGN];
+    __shared__ uint32_t park[PARK > 0 ? PARK : 1][PARK > 0 ? (size_t)BLK * E : 1];
     const uint32_t tid = threadIdx.x & (TPP - 1), pl = threadIdx.x / TPP;
     uint32_t *lds = lds_all + ((size_t)pl << LOGN);
     const uint32_t sub = blockIdx.x * PPB + pl;
     const uint32_t subc = sub < batch ? sub : batch - 1;  // ragged tail: recompute the last polynomial, store nothing
     const W *lp = lhs + ((size_t)subc << LOGN), *rp = rhs + ((size_t)subc << LOGN);
     const uint32_t ebase = pdep<FULL & ~RM0>(tid);
-    uint32_t res[KP][E];
+    uint32_t res[KP - PARK][E];
     static_for<0, KP>([&](auto ic) {
         constexpr int i = ic.value;
         uint32_t a[E], b[E];
@@ -162,8 +165,13 @@ __global__ __launch_bounds__(BLK, 2) void native_polymul_kernel(typename NativeS
         Wf::wsync();
         Wi::template pass<0, true, false>(a, lds, tid, F.twi[i], nullptr, F.P[i]);
         Wf::wsync();
+        if constexpr (i < PARK) {
 #pragma unroll
-        for (int j = 0; j < E; ++j) res[i][j] = a[j];
+            for (int j = 0; j < E; ++j) park[i][(size_t)j * BLK + threadIdx.x] = a[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < E; ++j) res[i - PARK][j] = a[j];
+        }
     });
     if (sub < batch) {
         W *op = prod + ((size_t)sub << LOGN);
@@ -171,7 +179,7 @@ __global__ __launch_bounds__(BLK, 2) void native_polymul_kernel(typename NativeS
         for (int j = 0; j < E; ++j) {
             uint32_t r[KP];
 #pragma unroll
-            for (int i = 0; i < KP; ++i) r[i] = res[i][j];
+            for (int i = 0; i < KP; ++i) r[i] = i < PARK ? park[i < PARK ? i : 0][(size_t)j * BLK + threadIdx.x] : res[i < PARK ? 0 : i - PARK][j];
             op[ebase | cdep((uint32_t)j, RM0)] = crt_regs<SH>(r, C);
         }
     }
