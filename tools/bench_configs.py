@@ -142,6 +142,7 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["p64", "p32", "c4", "c3", "c5", "prod", "ext"]
     if "pext" in which:
         product_ext_case(2048, [4294955009, 4294914049], 6, 2, 4096, "product u32x2")
+        product_ext_case(2048, [1073479681, 1062862849], 6, 2, 4096, "product u30x2")
         product_ext_case(2048, [18446744069414584321], 6, 2, 4096, "product u64x1 (Solinas)")
         product_ext_case(1024, [4611686018427322369], 6, 2, 8192, "product u64x1 (62-bit)")
     if "ext" in which:
