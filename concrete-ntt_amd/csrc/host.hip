@@ -883,7 +883,7 @@ extern "C" int cntt_native_reserve(const cntt_native_t *pl, size_t batch) {
 }
 
 // negacyclic_polymul on device memory: src/native64.rs:1042-1069 batched
-// whole product in one kernel (native_fused.hpp) for the Plan32 kinds with 32/64-bit words, 32 <= n <= 4096
+// whole product in one kernel (native_fused.hpp) for the Plan32 kinds except native128, 32 <= n <= 4096
 template <int KIND>
 static hipError_t native_fused_try(const cntt_native *pl, void *prod, const void *lhs, const void *rhs, size_t batch,
                                    hipStream_t st, int *rc_out) {
@@ -905,7 +905,7 @@ static hipError_t native_fused_try(const cntt_native *pl, void *prod, const void
 
 static int native_polymul_device(const cntt_native *pl, void *prod, const void *lhs, const void *rhs, size_t batch,
                                  hipStream_t st) {
-    if (batch > 0 && batch < ((size_t)1 << 32) && !pl->info.is52 && pl->info.word <= 8) {
+    if (batch > 0 && batch < ((size_t)1 << 32) && !pl->info.is52) {
         int rc = CNTT_OK;
         hipError_t e = hipErrorNotSupported;
         switch (pl->kind) {
@@ -913,6 +913,7 @@ static int native_polymul_device(const cntt_native *pl, void *prod, const void *
         case CNTT_NATIVE64_PLAN32: e = native_fused_try<1>(pl, prod, lhs, rhs, batch, st, &rc); break;
         case CNTT_NATIVE_BINARY32_PLAN32: e = native_fused_try<3>(pl, prod, lhs, rhs, batch, st, &rc); break;
         case CNTT_NATIVE_BINARY64_PLAN32: e = native_fused_try<4>(pl, prod, lhs, rhs, batch, st, &rc); break;
+        case CNTT_NATIVE_BINARY128_PLAN32: e = native_fused_try<5>(pl, prod, lhs, rhs, batch, st, &rc); break;
         default: break;
         }
         if (rc != CNTT_OK) return rc;

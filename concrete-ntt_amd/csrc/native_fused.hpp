@@ -46,6 +46,18 @@ template <> struct NativeShape<4> {  // native_binary64::Plan32
     static constexpr int gb(int) { return -1; }
 };
 
+struct alignas(16) Word128 {  // u128 as Rust lays it out on x86-64: 16-byte little-endian (lo, hi)
+    uint64_t lo, hi;
+};
+template <> struct NativeShape<5> {  // native_binary128::Plan32: digits P0, (P1,P2), (P3,P4), u128 words
+    using W = Word128;
+    static constexpr int KP = 5, NG = 3;
+    static constexpr uint32_t PAIRS = 0b110u;
+    static constexpr bool BINARY = true;
+    static constexpr int ga(int g) { return g == 0 ? 0 : g == 1 ? 1 : 3; }
+    static constexpr int gb(int g) { return g == 0 ? -1 : g == 1 ? 2 : 4; }
+};
+
 template <int KP> struct FusedTables {
     const TwPair<uint32_t> *twf[KP], *twi[KP];
     ModParams<uint32_t> P[KP];
@@ -54,7 +66,13 @@ template <int KP> struct FusedTables {
 // value % P_k for a u32 / u64 word, canonical (split_kernel's 30-bit-prime branch)
 template <class W> __device__ __forceinline__ uint32_t split30(W w, const SplitArgs &A, int k) {
     const uint32_t p = (uint32_t)A.prime[k];
-    if constexpr (sizeof(W) == 4) {
+    if constexpr (sizeof(W) == 16) {
+        uint32_t acc = (uint32_t)(w.hi >> 32);
+        acc = fold32(acc, (uint32_t)w.hi, p, A.c[k], A.c_shoup[k], A.one_shoup[k]);
+        acc = fold32(acc, (uint32_t)(w.lo >> 32), p, A.c[k], A.c_shoup[k], A.one_shoup[k]);
+        acc = fold32(acc, (uint32_t)w.lo, p, A.c[k], A.c_shoup[k], A.one_shoup[k]);
+        return canon4(acc, p);
+    } else if constexpr (sizeof(W) == 4) {
         return canon4(red32_lazy((uint32_t)w, p, A.one_shoup[k]), p);
     } else {
         const uint32_t acc = fold32((uint32_t)((uint64_t)w >> 32), (uint32_t)w, p, A.c[k], A.c_shoup[k], A.one_shoup[k]);
@@ -115,11 +133,20 @@ template <class SH> __device__ __forceinline__ typename SH::W crt_regs(const uin
         }
     }
     const bool sign = v[NG - 1] > (A.M[NG - 1] / 2);
-    uint64_t pos = v[0];  // words are at most 64 bits here: the recombination wraps modulo 2^64
+    if constexpr (sizeof(typename SH::W) == 16) {  // recombination modulo 2^128
+        u128d pos = {v[0], 0};
 #pragma unroll
-    for (int g = 1; g < NG; ++g) pos += v[g] * A.prefix_lo[g];
-    const uint64_t out = sign ? pos - A.prefix_lo[NG] : pos;
-    return (typename SH::W)out;
+        for (int g = 1; g < NG; ++g) pos = add128(pos, mul_64x128(v[g], A.prefix_lo[g], A.prefix_hi[g]));
+        const u128d full = {A.prefix_lo[NG], A.prefix_hi[NG]};
+        const u128d out = sign ? sub128(pos, full) : pos;
+        return typename SH::W{out.lo, out.hi};
+    } else {  // words of at most 64 bits: the recombination wraps modulo 2^64
+        uint64_t pos = v[0];
+#pragma unroll
+        for (int g = 1; g < NG; ++g) pos += v[g] * A.prefix_lo[g];
+        const uint64_t out = sign ? pos - A.prefix_lo[NG] : pos;
+        return (typename SH::W)out;
+    }
 }
 
 // PARK: the first PARK finished residue tiles wait for the CRT in LDS (thread-private slots, no synchronisation)
@@ -157,7 +184,12 @@ __global__ __launch_bounds__(BLK, 2) void native_polymul_kernel(typename NativeS
 #pragma unroll
         for (int j = 0; j < E; ++j) {
             const W w = rp[ebase | cdep((uint32_t)j, RM0)];
-            b[j] = SH::BINARY ? (uint32_t)w : split30<W>(w, S, i);  // `as u32`: src/native_binary64.rs:379-385
+            if constexpr (SH::BINARY) {  // `as u32`: src/native_binary64.rs:379-385, src/native_binary128.rs:100-106
+                if constexpr (sizeof(W) == 16) b[j] = (uint32_t)w.lo;
+                else b[j] = (uint32_t)w;
+            } else {
+                b[j] = split30<W>(w, S, i);
+            }
         }
         Wf::template pass<0, false, false>(b, lds, tid, F.twf[i], nullptr, F.P[i]);
 #pragma unroll
