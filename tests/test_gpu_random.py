@@ -158,7 +158,11 @@ def test_gpu_random_product_plans(oracle, seed):
     n = 1 << rng.randint(5, 11)
     k = rng.randint(1, 4)
     lp = oracle.largest_prime_in_arithmetic_progression64
+    tries = 0
     while True:
+        tries += 1
+        if tries % 100 == 0 and k > 1:
+            k -= 1  # too few NTT primes of that width for this size (e.g. four below 2^16 at n = 2048)
         bits_each = 64 // k
         primes = set()
         for _ in range(k):
