@@ -10,10 +10,16 @@ plus the pointwise pass (which is inside the timed region and earns no units).  
 N GPUs: one process per GPU, each owns its own shard of `batch` polynomials (independent units, no
 collective on the data path) -> weak scaling.  Timing: barrier + synchronize on both sides of exactly
 K steps, max over ranks, rank 0 prints one JSON line.
+
+Launch: `python bench.py --gpus N` from a plain shell starts the N ranks itself (fresh child processes, started
+before this process touches the GPU; rendezvous on 127.0.0.1); under `python -m torch.distributed.run` the ranks
+already exist (WORLD_SIZE is set) and this file is rank code only.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,6 +30,8 @@ if ROOT not in sys.path:
 P62 = 4611686018427322369   # benches/ntt.rs:115  largest prime = 1 mod 2^16 below 2^62
 N = 1024
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+METRIC = "forward+inverse NTTs/sec (prime64, N=1024, batched) per GPU; % HBM roofline"
+PMC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # rocprofv3 --pmc results of the committed build
 
 
 def usable_cpus():
@@ -100,33 +108,266 @@ def cpu_baseline(n, p, seconds_budget=12.0):
     return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=65536, help="polynomials per GPU")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
-                    help="nccl (= RCCL, one rank per GPU) is what the driver uses; gloo lets several ranks share one "
-                         "GPU to rehearse the multi-process path on a 1-GPU box")
-    ap.add_argument("--ramp-seconds", type=float, default=2.0,
-                    help="untimed back-to-back steps before the W warm-up steps, so that the timed region "
-                         "runs at the steady-state DVFS clock instead of inside the ramp from idle")
-    args = ap.parse_args()
+# ---------------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` with no WORLD_SIZE in the environment
+# ---------------------------------------------------------------------------------------------------------
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(world, argv, timeout_s):
+    """Start `world` fresh rank processes (this process has not touched the GPU and never will), wait for all of
+    them, and return non-zero if any rank failed.  Rank 0 inherits stdout, so its JSON line is this command's."""
+    port = free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    deadline = time.monotonic() + timeout_s
+    rc = 0
+    pending = set(range(world))
+    while pending:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is not None:
+                pending.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    sys.stderr.write("bench.py: rank %d exited with status %d; stopping the other ranks\n" % (r, code))
+        if rc != 0 or time.monotonic() > deadline:
+            if rc == 0:
+                rc = 124
+                sys.stderr.write("bench.py: ranks did not finish within %d s\n" % timeout_s)
+            for r in pending:
+                procs[r].terminate()
+            for r in pending:
+                try:
+                    procs[r].wait(10)
+                except subprocess.TimeoutExpired:
+                    procs[r].kill()
+            break
+        time.sleep(0.05)
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------------------
+# rank code
+# ---------------------------------------------------------------------------------------------------------
+class stdout_to_stderr:
+    """gloo announces its connections on the C-level stdout; keep this command's stdout to the one JSON line."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
+class Timer:
+    """HIP-event timing on the stream the library launches on (torch's current stream of the device: the stream
+    `buffer_info` hands to every `_batch` call)."""
+
+    def __init__(self, torch):
+        self.torch = torch
+
+    def ramp(self, fn, seconds):
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            for _ in range(10):
+                fn()
+            self.torch.cuda.synchronize()
+
+    def ms(self, fn, reps, ramp_s=0.0):
+        torch = self.torch
+        if ramp_s > 0:
+            self.ramp(fn, ramp_s)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+
+def pmc_traffic(kernel_key, batch):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes of THIS build (FETCH_SIZE doubled for gfx950 +
+    WRITE_SIZE, MI355X_MICROARCH.md section HBM); None when no such profile is committed for the kernel/batch."""
+    try:
+        with open(PMC_FILE) as f:
+            table = json.load(f)
+        e = table[kernel_key]
+        if int(e["batch"]) != int(batch):
+            return None, None
+        return float(e["hbm_bytes_per_launch"]), e.get("source")
+    except (OSError, KeyError, ValueError, TypeError):
+        return None, None
+
+
+def extra_configs(args, torch, cntt, timer, rank, world, dist, dev):
+    """The other BASELINE.json configs, timed after the headline region (HIP events, steady-state clocks):
+    C3 native64 N=4096, C5 native_binary64 N=2048 (N=1 only), C4 prime64 N=16384 shard-resident (every rank) and --
+    with more than one rank -- C4 end to end: scatter from rank 0, transform, gather back."""
+    from concrete_ntt_amd import native64, native_binary64, prime64, shard
+    out = []
+
+    def native_case(name, cls, n, batch, binary):
+        plan = cls.try_new(n)
+        lhs = torch.empty(batch * n, dtype=torch.int64, device=dev)
+        rhs = torch.empty(batch * n, dtype=torch.int64, device=dev)
+        prod = torch.empty(batch * n, dtype=torch.int64, device=dev)
+        cntt.fill_uniform(lhs, 0, 0x5EED0003)
+        cntt.fill_uniform(rhs, 0, 0x5EED1003)
+        if binary:
+            rhs &= 1
+        plan.reserve(batch)
+        ms = timer.ms(lambda: plan.negacyclic_polymul_batch(prod, lhs, rhs), 5, ramp_s=0.5)
+        by = 3 * n * 8 * batch
+        out.append({"config": name, "workload": "%s negacyclic_polymul N=%d batch=%d, device-resident" % (name, n, batch),
+                    "ms_per_batch": ms, "value": batch / (ms * 1e-3), "unit": "polymul/s",
+                    "algorithmic_bytes": by, "roofline_frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
+        del lhs, rhs, prod, plan
+
+    if world == 1 and not args.no_extra:
+        for name, cls, n, batch, binary in (("C3 native64::Plan32", native64.Plan32, 4096, 16384, False),
+                                            ("C5 native_binary64::Plan32", native_binary64.Plan32, 2048, 65536, True)):
+            try:
+                native_case(name, cls, n, batch, binary)
+            except Exception as e:  # an extra never costs the headline line
+                out.append({"config": name, "error": repr(e)})
+            torch.cuda.empty_cache()
+    if args.no_extra:
+        return out
+
+    # C4: prime64 N=16384, 2^20 polynomials over 8 GPUs = 131072 per GPU (16 GiB in place)
+    n4, per_gpu = 16384, args.c4_batch
+    try:
+        plan = prime64.Plan.try_new(n4, P62)
+        a = torch.empty(per_gpu * n4, dtype=torch.int64, device=dev)
+        cntt.fill_uniform(a, P62, 0x5EED0004 + rank * per_gpu * n4)
+        reps = 3
+        fwd_ms = timer.ms(lambda: plan.fwd_batch(a), reps, ramp_s=0.3)
+        inv_ms = timer.ms(lambda: plan.inv_batch(a), reps)
+        t = torch.tensor([fwd_ms, inv_ms], dtype=torch.float64)
+        if dist is not None:
+            t = t.to(dev) if args.dist_backend == "nccl" else t
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            t = t.cpu()
+        fwd_ms, inv_ms = float(t[0]), float(t[1])
+        by = 2 * n4 * 8 * per_gpu
+        out.append({"config": "C4 prime64 N=16384 shard-resident",
+                    "workload": "prime64 N=16384 p=%d, %d polynomials per GPU (%.1f GiB in place) x %d GPU(s): fwd and inv "
+                                "timed separately, max over ranks" % (P62, per_gpu, per_gpu * n4 * 8 / 2**30, world),
+                    "fwd_ms": fwd_ms, "inv_ms": inv_ms,
+                    "value": world * 2 * per_gpu / ((fwd_ms + inv_ms) * 1e-3), "unit": "NTT/s", "n_gpus": world,
+                    "fwd_roofline_frac": by / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "inv_roofline_frac": by / (inv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
+        if dist is not None:
+            # end to end: the whole batch starts and ends on rank 0
+            total = world * per_gpu
+            full = None
+            if rank == 0:
+                full = torch.empty(total * n4, dtype=torch.int64, device=dev)
+                cntt.fill_uniform(full, P62, 0x5EED0C04)
+            else:
+                full = torch.empty(0, dtype=torch.int64, device=dev)
+
+            def fence():
+                torch.cuda.synchronize()
+                dist.barrier()
+                torch.cuda.synchronize()
+
+            for it in range(2):   # first pass creates the point-to-point channels; the second is the one reported
+                fence()
+                t0 = time.perf_counter()
+                mine = shard.scatter_batch(full, n4, src=0)
+                fence()
+                t1 = time.perf_counter()
+                plan.fwd_batch(mine)
+                fence()
+                t2 = time.perf_counter()
+                got = shard.gather_batch(mine, n4, total, dst=0, out=full if rank == 0 else None)
+                fence()
+                t3 = time.perf_counter()
+                del mine, got
+            tt = torch.tensor([t1 - t0, t2 - t1, t3 - t2], dtype=torch.float64)
+            tt = tt.to(dev) if args.dist_backend == "nccl" else tt
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            sc, co, ga = [float(x) for x in tt.cpu()]
+            out.append({"config": "C4 prime64 N=16384 end to end",
+                        "workload": "%d polynomials (%.0f GiB) on rank 0 -> scatter over %d ranks -> fwd -> gather to rank 0"
+                                    % (total, total * n4 * 8 / 2**30, world),
+                        "scatter_s": sc, "compute_s": co, "gather_s": ga,
+                        "value": total / (sc + co + ga), "unit": "NTT/s (end to end, one fwd per polynomial)",
+                        "compute_only_value": total / co, "n_gpus": world})
+            del full
+        del a
+    except Exception as e:
+        out.append({"config": "C4 prime64 N=16384", "error": repr(e)})
+    torch.cuda.empty_cache()
+    return out
+
+
+def dry_run(args, world, rank):
+    """Rehearsal of the launch / rendezvous / max-over-ranks / one-JSON-line plumbing with NO transform executed (for the
+    CPU tests: this container has no GPU and there is no CPU compute path).  The line says so and carries no value."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        with stdout_to_stderr():
+            dist.init_process_group(backend="gloo")
+            dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * args.steps)
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        print(json.dumps({"metric": METRIC, "value": None, "unit": "NTT/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "u64", "data": "none", "dry_run": True,
+                          "config": {"workload": "DRY RUN: launch plumbing only, no transform executed"}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run_rank(args):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d; the launcher's world size is used\n" % (args.gpus, world))
+    if args.dry_run:
+        return dry_run(args, world, rank)
 
     import torch
     import concrete_ntt_amd as cntt
     from concrete_ntt_amd import prime64
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     ndev = torch.cuda.device_count()
     if args.dist_backend == "gloo":
         local_rank = local_rank % max(ndev, 1)   # rehearsal mode: ranks may share a GPU
+    elif local_rank >= ndev:
+        raise SystemExit("bench.py: rank %d needs GPU %d but only %d are visible (one rank per GPU with nccl)"
+                         % (rank, local_rank, ndev))
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
@@ -135,11 +376,15 @@ def main():
         if args.dist_backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
-            dist.init_process_group(backend="gloo")
+            with stdout_to_stderr():
+                dist.init_process_group(backend="gloo")
+                dist.barrier()
+        assert dist.get_world_size() == world
 
     batch = args.batch
     plan = prime64.Plan.try_new(N, P62)
     dev = torch.device("cuda", local_rank)
+    timer = Timer(torch)
     a = torch.empty(batch * N, dtype=torch.int64, device=dev)
     b = torch.empty(batch * N, dtype=torch.int64, device=dev)
     # every rank owns a different shard of the synthetic stream
@@ -163,11 +408,7 @@ def main():
 
     # device clock ramp (untimed): the GPU idles at ~100 MHz and the package power controller needs
     # hundreds of milliseconds of sustained load to settle (profiles/r01_power_clock_lab.txt)
-    t_ramp = time.perf_counter()
-    while time.perf_counter() - t_ramp < args.ramp_seconds:
-        for _ in range(20):
-            step()
-        torch.cuda.synchronize()
+    timer.ramp(step, args.ramp_seconds)
     for _ in range(args.warmup):
         step()
     fence()
@@ -191,25 +432,30 @@ def main():
 
     # per-kernel timing with HIP events on the launch stream (roofline leg), after the timed region
     reps = 50
-    fused_ms = plan.time_batch(5, a, rhs=b, reps=reps) / reps
-    fwd_ms = plan.time_batch(0, a, reps=reps) / reps
-    inv_ms = plan.time_batch(1, a, reps=reps) / reps
-    mul_ms = plan.time_batch(2, a, rhs=b, reps=reps) / reps
+    fused_ms = timer.ms(step, reps)
+    fwd_ms = timer.ms(lambda: plan.fwd_batch(a), reps)
+    inv_ms = timer.ms(lambda: plan.inv_batch(a), reps)
+    mul_ms = timer.ms(lambda: plan.mul_assign_normalize_batch(a, b), reps)
     alg_bytes = 2 * N * 8 * batch                     # 2*N*sizeof(T) = 16384 B per transform
     # Dominant kernel of the timed region = the fused step kernel: 2 transforms per polynomial per launch.
-    # roofline.achieved = per-transform algorithmic bytes x transforms per launch / launch time (the kernel
-    # itself moves only 3*N*8 bytes per polynomial -- read lhs, read rhs_ntt, write lhs -- which is what
-    # `traffic` reports from the rocprofv3 PMC passes).
+    # roofline.achieved = per-transform algorithmic bytes x transforms per launch / launch time (the task's
+    # definition).  The kernel itself moves only 3*N*8 bytes per polynomial -- read lhs, read rhs_ntt, write lhs --
+    # which is `moved_bytes_*` (the real HBM rate) and what `traffic` reports from the rocprofv3 PMC passes.
     fused_alg = 2 * alg_bytes
     achieved = fused_alg / (fused_ms * 1e-3) / 1e9
-    # HBM bytes per launch measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes; FETCH_SIZE
-    # doubled on gfx950) for exactly this kernel and batch: profiles/r01_v3_rocprofv3_summary.txt
-    traffic = (2 * 524748.2 + 524288.0) * 1024 if batch == 65536 else None
+    moved = 3 * N * 8 * batch
+    traffic, traffic_src = pmc_traffic("mul_kernel_wp_u64_logn10_lazy", batch)
+
+    extras = []
+    try:
+        extras = extra_configs(args, torch, cntt, timer, rank, world, dist, dev)
+    except Exception as e:
+        extras = [{"config": "extras", "error": repr(e)}]
 
     if rank == 0:
         units = world * 2 * batch * args.steps        # forward + inverse transforms, all ranks
         out = {
-            "metric": "forward+inverse NTTs/sec (prime64, N=1024, batched) per GPU; % HBM roofline",
+            "metric": METRIC,
             "value": units / elapsed, "unit": "NTT/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
@@ -219,19 +465,27 @@ def main():
                                    "mul_assign_normalize (pre-transformed rhs) + inv, device-resident, fused in one "
                                    "kernel (cntt_prime64_mul_ntt_batch)" % batch,
                        "polynomial_size": N, "batch_per_gpu": batch, "modulus": P62,
-                       "sharding": "independent batch shards, no collective"},
+                       "sharding": "independent batch shards, no collective",
+                       "launcher": "torchrun" if os.environ.get("TORCHELASTIC_RUN_ID") else
+                                   ("bench.py --gpus" if world > 1 else "single process"),
+                       "dist_backend": args.dist_backend if world > 1 else None},
             "per_gpu_value": units / elapsed / world,
             "unfused_value": units / unfused, "unfused_ms_per_step": 1e3 * unfused / args.steps,
             "roofline": {"bound": "hbm", "kernel": "mul_kernel_wp<u64, LOGN=10, lazy> (fwd + pointwise + inv fused)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "limiter": "VALU issue of the 62-bit Shoup butterflies under the package power cap (DESIGN.md 5); "
+                                    "HBM is the stated roofline",
                          "algorithmic_bytes_per_launch": fused_alg, "avg_launch_ms": fused_ms,
                          "transforms_per_launch": 2 * batch,
-                         "moved_bytes_frac": 3 * N * 8 * batch / (fused_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "moved_bytes_per_launch": moved,
+                         "moved_bytes_achieved": moved / (fused_ms * 1e-3) / 1e9,
+                         "moved_bytes_frac": moved / (fused_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "fwd_kernel_ms": fwd_ms, "fwd_frac": alg_bytes / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "inv_kernel_ms": inv_ms, "inv_frac": alg_bytes / (inv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "pointwise_kernel_ms": mul_ms,
                          "pointwise_frac": 3 * N * 8 * batch / (mul_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "configs": extras,
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
@@ -243,6 +497,34 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=65536, help="polynomials per GPU")
+    ap.add_argument("--c4-batch", type=int, default=131072,
+                    help="polynomials per GPU of the C4 extra (prime64 N=16384; 131072 = 2^20 / 8 GPUs = 16 GiB)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the C3 / C4 / C5 extras (the `configs` array)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL, one rank per GPU) is what the driver uses; gloo lets several ranks share one "
+                         "GPU to rehearse the multi-process path on a 1-GPU box")
+    ap.add_argument("--ramp-seconds", type=float, default=2.0,
+                    help="untimed back-to-back steps before the W warm-up steps, so that the timed region "
+                         "runs at the steady-state DVFS clock instead of inside the ramp from idle")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launch / rendezvous plumbing only (gloo, no GPU, no transform); prints a line with value null")
+    ap.add_argument("--launch-timeout", type=int, default=1500, help="seconds the launcher waits for its ranks")
+    args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: become the launcher.  Nothing above has imported torch or touched HIP.
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:], args.launch_timeout))
+    run_rank(args)
 
 
 if __name__ == "__main__":

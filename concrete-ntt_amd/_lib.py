@@ -77,7 +77,6 @@ def lib():
             "mul_accumulate_batch": (c_int, [c_vp, c_vp, c_vp, c_vp, c_sz, c_int, c_vp]),
             "mul_ntt_batch": (c_int, [c_vp, c_vp, c_vp, c_sz, c_int, c_vp]),
             "external_product_batch": (c_int, [c_vp, c_vp, c_vp, c_vp, c_sz, c_sz, c_sz, c_int, c_int, c_vp]),
-            "time_batch": (c_int, [c_vp, c_int, c_vp, c_vp, c_sz, c_int, c_vp, c_vp]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, p + name)
@@ -162,6 +161,11 @@ def buffer_info(buf):
         stream = None
         if buf.is_cuda:
             import torch
+            # the library keys its per-device plan replicas on the CURRENT HIP device and launches there
+            if buf.device.index != torch.cuda.current_device():
+                raise ValueError("tensor lives on cuda:%d but the current device is cuda:%d: call "
+                                 "torch.cuda.set_device (or use torch.cuda.device) first"
+                                 % (buf.device.index, torch.cuda.current_device()))
             stream = torch.cuda.current_stream(buf.device).cuda_stream
         return buf.data_ptr(), buf.numel(), buf.element_size(), where, stream
     if not buf.flags["C_CONTIGUOUS"]:

@@ -48,9 +48,9 @@ class NativePlan:
         """ntt_0() .. ntt_k(): borrowed prime sub-plan (src/native64.rs:950-969)."""
         if self.RES == 8:
             h = lib().cntt_native_ntt64(self._h, i)
-            return _Plan64(h, owned=False) if h else None
+            return _Plan64(h, owned=False, parent=self) if h else None
         h = lib().cntt_native_ntt32(self._h, i)
-        return _Plan32(h, owned=False) if h else None
+        return _Plan32(h, owned=False, parent=self) if h else None
 
     # -- helpers -----------------------------------------------------------------------------
     @property
@@ -78,25 +78,31 @@ class NativePlan:
             ptrs.append(ptr)
         return (ctypes.c_void_p * self.NPRIMES)(*ptrs)
 
-    # -- the reference's slice API -------------------------------------------------------------
+    # -- the reference's slice API (host memory: the C entry points take host pointers) -------------
+    def _host_words(self, buf, what):
+        ptr, count, where, _ = self._words(buf)
+        if where != _lib.MEM_HOST:
+            raise TypeError("%s() takes host slices; use %s_batch() for device tensors" % (what, what))
+        return ptr, count, where
+
     def fwd(self, value, *residues):
-        ptr, count, where, _ = self._words(value)
+        ptr, count, where = self._host_words(value, "fwd")
         check(lib().cntt_native_fwd(self._h, ptr, count, self._res(residues, where, count)))
 
     def fwd_binary(self, value, *residues):
         if not self.BINARY:
             raise AttributeError("fwd_binary exists only on native_binary* plans")
-        ptr, count, where, _ = self._words(value)
+        ptr, count, where = self._host_words(value, "fwd")
         check(lib().cntt_native_fwd_binary(self._h, ptr, count, self._res(residues, where, count)))
 
     def inv(self, value, *residues):
-        ptr, count, where, _ = self._words(value)
+        ptr, count, where = self._host_words(value, "inv")
         check(lib().cntt_native_inv(self._h, ptr, count, self._res(residues, where, count)))
 
     def negacyclic_polymul(self, prod, lhs, rhs):
-        pp, pc, _, _ = self._words(prod)
-        lp, lc, _, _ = self._words(lhs)
-        rp, rc_, _, _ = self._words(rhs)
+        pp, pc, _ = self._host_words(prod, "negacyclic_polymul")
+        lp, lc, _ = self._host_words(lhs, "negacyclic_polymul")
+        rp, rc_, _ = self._host_words(rhs, "negacyclic_polymul")
         check(lib().cntt_native_negacyclic_polymul(self._h, pp, pc, lp, lc, rp, rc_))
 
     # -- batched --------------------------------------------------------------------------------

@@ -13,8 +13,10 @@ class PrimePlan:
 
     BITS = 64
 
-    def __init__(self, handle, owned=True):
-        self._h, self._owned = handle, owned
+    def __init__(self, handle, owned=True, parent=None):
+        # a borrowed sub-plan (native ntt_i(), product plan_32()/plan_64()) keeps its parent alive: the C++ object
+        # belongs to the parent and is freed with it
+        self._h, self._owned, self._parent = handle, owned, parent
         self._p = "cntt_prime%d_" % self.BITS
         self._n = getattr(lib(), self._p + "ntt_size")(handle)
 
@@ -72,32 +74,35 @@ class PrimePlan:
             raise TypeError("expected %d-byte elements" % (self.BITS // 8))
         return ptr, count, where, stream
 
-    # -- the reference's slice API (host memory, one polynomial) -------------------------------
-    def fwd(self, buf):
+    def _host(self, buf, what):
+        """Argument of the reference's slice API: a host array (the C entry points take host pointers)."""
         ptr, count, where, _ = self._arg(buf)
         if where != _lib.MEM_HOST:
-            raise TypeError("fwd() takes a host slice; use fwd_batch() for device tensors")
+            raise TypeError("%s() takes host slices; use %s_batch() for device tensors" % (what, what))
+        return ptr, count
+
+    # -- the reference's slice API (host memory, one polynomial) -------------------------------
+    def fwd(self, buf):
+        ptr, count = self._host(buf, "fwd")
         check(getattr(lib(), self._p + "fwd")(self._h, ptr, count))
 
     def inv(self, buf):
-        ptr, count, where, _ = self._arg(buf)
-        if where != _lib.MEM_HOST:
-            raise TypeError("inv() takes a host slice; use inv_batch() for device tensors")
+        ptr, count = self._host(buf, "inv")
         check(getattr(lib(), self._p + "inv")(self._h, ptr, count))
 
     def mul_assign_normalize(self, lhs, rhs):
-        lp, lc, _, _ = self._arg(lhs)
-        rp, rc_, _, _ = self._arg(rhs)
+        lp, lc = self._host(lhs, "mul_assign_normalize")
+        rp, rc_ = self._host(rhs, "mul_assign_normalize")
         check(getattr(lib(), self._p + "mul_assign_normalize")(self._h, lp, lc, rp, rc_))
 
     def normalize(self, values):
-        vp, vc, _, _ = self._arg(values)
+        vp, vc = self._host(values, "normalize")
         check(getattr(lib(), self._p + "normalize")(self._h, vp, vc))
 
     def mul_accumulate(self, acc, lhs, rhs):
-        ap, ac, _, _ = self._arg(acc)
-        lp, lc, _, _ = self._arg(lhs)
-        rp, rc_, _, _ = self._arg(rhs)
+        ap, ac = self._host(acc, "mul_accumulate")
+        lp, lc = self._host(lhs, "mul_accumulate")
+        rp, rc_ = self._host(rhs, "mul_accumulate")
         check(getattr(lib(), self._p + "mul_accumulate")(self._h, ap, ac, lp, lc, rp, rc_))
 
     # -- batched API: `batch` polynomials back to back, host arrays or device tensors ----------
@@ -153,14 +158,3 @@ class PrimePlan:
         if lb != batch or rb != batch or lw != where or rw != where:
             raise Panic("acc, lhs and rhs must have the same shape and live in the same memory")
         check(getattr(lib(), self._p + "mul_accumulate_batch")(self._h, ap, lp, rp, batch, where, stream))
-
-    def time_batch(self, op, bufs, rhs=None, reps=1):
-        """HIP-event time (ms) of `reps` back-to-back launches on the tensor's stream.
-        op: 0 fwd, 1 inv, 2 mul_assign_normalize, 5 fused mul_ntt."""
-        ptr, batch, where, stream = self._batch(bufs)
-        if where != _lib.MEM_DEVICE:
-            raise TypeError("time_batch needs device memory")
-        rp = self._batch(rhs)[0] if rhs is not None else None
-        ms = ctypes.c_float(0)
-        check(getattr(lib(), self._p + "time_batch")(self._h, op, ptr, rp, batch, reps, stream, ctypes.byref(ms)))
-        return ms.value

@@ -439,28 +439,6 @@ template <class T> static int plan_table(const PrimePlan<T> *pl, cntt_table_t wh
     return CNTT_OK;
 }
 
-template <class T>
-static int time_batch(const PrimePlan<T> *pl, int op, T *bufs, const T *rhs, size_t batch, int reps, hipStream_t st,
-                      float *ms_out) {
-    if (!pl || !bufs || !ms_out || reps < 1) return fail(CNTT_EINVAL, "bad argument");
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
-    int rc = CNTT_OK;
-    (void)hipEventRecord(e0, st);
-    for (int r = 0; r < reps && rc == CNTT_OK; ++r)
-        rc = prime_op<T>(pl, op, bufs, rhs, nullptr, batch * pl->n, batch, CNTT_MEM_DEVICE, st);
-    (void)hipEventRecord(e1, st);
-    if (rc == CNTT_OK) {
-        hipError_t e = hipEventSynchronize(e1);
-        if (e == hipSuccess) e = hipEventElapsedTime(ms_out, e0, e1);
-        if (e != hipSuccess) rc = fail(CNTT_EDEVICE, "event timing failed: %s", hipGetErrorString(e));
-    }
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    return rc;
-}
-
 // ---- C ABI: prime64 ---------------------------------------------------------------------------
 #define CNTT_PRIME_API(BITS, T, PLAN)                                                                               \
     extern "C" int cntt_prime##BITS##_plan_new(size_t n, T p, PLAN **out) { return plan_new<T, PLAN>(n, p, out); }  \
@@ -526,10 +504,6 @@ static int time_batch(const PrimePlan<T> *pl, int op, T *bufs, const T *rhs, siz
                                                             size_t nterms, size_t nout, size_t batch, int accumulate,  \
                                                             cntt_mem_t where, void *stream) {                          \
         return external_product<T>(pl, out, terms, key_ntt, nterms, nout, batch, accumulate, where, (hipStream_t)stream); \
-    }                                                                                                               \
-    extern "C" int cntt_prime##BITS##_time_batch(const PLAN *pl, int op, T *bufs, const T *rhs, size_t batch,       \
-                                                 int reps, void *st, float *ms) {                                   \
-        return time_batch<T>(pl, op, bufs, rhs, batch, reps, (hipStream_t)st, ms);                                  \
     }
 
 CNTT_PRIME_API(64, uint64_t, cntt_plan64)

@@ -88,11 +88,11 @@ class Plan:
 
     def plan_32(self):
         L = lib()
-        return [_Plan32(L.cntt_product_ntt32(self._h, i), owned=False) for i in range(L.cntt_product_nprimes32(self._h))]
+        return [_Plan32(L.cntt_product_ntt32(self._h, i), owned=False, parent=self) for i in range(L.cntt_product_nprimes32(self._h))]
 
     def plan_64(self):
         L = lib()
-        return [_Plan64(L.cntt_product_ntt64(self._h, i), owned=False) for i in range(L.cntt_product_nprimes64(self._h))]
+        return [_Plan64(L.cntt_product_ntt64(self._h, i), owned=False, parent=self) for i in range(L.cntt_product_nprimes64(self._h))]
 
     def modular_inverses(self):
         k = len(self.primes())

@@ -252,11 +252,6 @@ int cntt_product_external_product_batch(const cntt_product_t *plan, uint64_t *ou
  * u32 variant: ((splitmix64(seed + i) >> 32) * bound) >> 32.  Device memory only. */
 int cntt_fill_uniform_u64(uint64_t *dst, size_t count, uint64_t bound, uint64_t seed, void *stream);
 int cntt_fill_uniform_u32(uint32_t *dst, size_t count, uint32_t bound, uint64_t seed, void *stream);
-/* HIP-event timing on the stream the kernels run on (bench.py roofline leg): elapsed milliseconds
- * of `reps` back-to-back launches of one batched operation. op: 0 fwd, 1 inv, 2 mul_assign_normalize, 5 mul_ntt */
-int cntt_prime64_time_batch(const cntt_plan64_t *plan, int op, uint64_t *bufs, const uint64_t *rhs, size_t batch, int reps, void *stream, float *ms_out);
-int cntt_prime32_time_batch(const cntt_plan32_t *plan, int op, uint32_t *bufs, const uint32_t *rhs, size_t batch, int reps, void *stream, float *ms_out);
-
 #ifdef __cplusplus
 }
 #endif

@@ -1,34 +1,89 @@
 """bench.py contract: on a machine without a GPU it refuses to run (there is no CPU path to time); on the GPU it
 prints exactly one JSON line carrying the driver's keys, BASELINE.json's metric, and the roofline / cpu_baseline
-objects."""
+objects.  `--gpus N` from a plain shell starts N ranks itself; under torch.distributed.run it is rank code."""
 import json
 import os
+import socket
 import subprocess
 import sys
 
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def clean_env():
+    """An environment without any launcher variables: what the driver's plain `python bench.py --gpus N` sees."""
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    return env
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def one_json_line(stdout):
+    lines = [ln for ln in stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    return json.loads(lines[0])
+
+
+def test_launcher_starts_n_ranks_from_a_plain_shell():
+    """`python bench.py --gpus 2` with no WORLD_SIZE: the parent spawns 2 rank processes which rendezvous (gloo here;
+    --dry-run because this container has no GPU and there is no CPU compute path) and rank 0 prints ONE line with
+    n_gpus == 2."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-run", "--steps", "2", "--warmup", "0"],
+                       capture_output=True, text=True, cwd=ROOT, env=clean_env(), timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = one_json_line(r.stdout)
+    assert d["n_gpus"] == 2 and d["dry_run"] is True and d["value"] is None and d["steps"] == 2
+
+
+def test_rank_code_under_torch_distributed_run():
+    """The driver's N>1 form: torch.distributed.run starts the ranks, bench.py must not spawn again."""
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(free_port()), BENCH, "--gpus", "2", "--dry-run",
+                        "--steps", "1", "--warmup", "0"], capture_output=True, text=True, cwd=ROOT, env=clean_env(),
+                       timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = one_json_line(r.stdout)
+    assert d["n_gpus"] == 2 and d["dry_run"] is True
+
+
+def test_launcher_fails_when_a_rank_fails():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True,
+                       text=True, cwd=ROOT, env=clean_env(), timeout=300)
+    assert r.returncode != 0 and "no CPU fallback" in r.stderr
+    assert not r.stdout.strip()
 
 
 def test_bench_refuses_without_gpu():
     import torch
     if torch.cuda.is_available():
         pytest.skip("GPU present")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"],
-                       capture_output=True, text=True, cwd=ROOT)
+    r = subprocess.run([sys.executable, BENCH, "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, cwd=ROOT, env=clean_env())
     assert r.returncode != 0 and "no CPU fallback" in (r.stderr + r.stdout)
     assert not r.stdout.strip().startswith("{")
 
 
 @pytest.mark.gpu
 def test_bench_json_contract():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--ramp-seconds",
-                        "0.3", "--batch", "8192"], capture_output=True, text=True, cwd=ROOT, timeout=600)
+    r = subprocess.run([sys.executable, BENCH, "--steps", "3", "--warmup", "1", "--ramp-seconds",
+                        "0.3", "--batch", "8192", "--c4-batch", "512"], capture_output=True, text=True, cwd=ROOT,
+                       env=clean_env(), timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
-    assert len(lines) == 1, lines
-    d = json.loads(lines[0])
+    d = one_json_line(r.stdout)
     with open(os.path.join(ROOT, "BASELINE.json")) as f:
         base = json.load(f)
     assert d["metric"] == base["metric"] and d["unit"] == "NTT/s"
@@ -45,3 +100,35 @@ def test_bench_json_contract():
     assert cb["kind"] == "port" and cb["unit"] == "NTT/s" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
     # value = units processed / time: 2 transforms per polynomial per step
     assert abs(d["value"] - 2 * 8192 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    # the other BASELINE configs ride on the same line
+    names = [c.get("config", "") for c in d["configs"]]
+    assert any(n.startswith("C3") for n in names) and any(n.startswith("C5") for n in names)
+    assert any(n.startswith("C4") for n in names)
+    for c in d["configs"]:
+        assert "error" not in c, c
+    assert rf["moved_bytes_frac"] < rf["frac"]   # the fused kernel moves 24 KiB per 32 KiB of algorithmic bytes
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("launcher", ["self", "torchrun"])
+def test_two_ranks_on_the_gpu_box(launcher):
+    """world_size 2 through both launch forms; gloo so that both ranks may share the box's single GPU.  Checks the
+    multi-rank line (n_gpus, whole-job value) and the C4 legs: shard-resident and scatter -> fwd -> gather."""
+    tail = ["--gpus", "2", "--dist-backend", "gloo", "--steps", "2", "--warmup", "1", "--ramp-seconds", "0.2", "--batch",
+            "4096", "--c4-batch", "64", "--no-cpu-baseline"]
+    if launcher == "self":
+        cmd = [sys.executable, BENCH] + tail
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", str(free_port()), BENCH] + tail
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, env=clean_env(), timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = one_json_line(r.stdout)
+    assert d["n_gpus"] == 2 and d["value"] > 0 and "dry_run" not in d
+    assert abs(d["value"] - 2 * 2 * 4096 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    assert abs(d["per_gpu_value"] * 2 - d["value"]) / d["value"] < 1e-9
+    by_name = {c["config"]: c for c in d["configs"]}
+    assert "error" not in json.dumps(d["configs"]), d["configs"]
+    e2e = by_name["C4 prime64 N=16384 end to end"]
+    assert e2e["n_gpus"] == 2 and e2e["scatter_s"] > 0 and e2e["compute_s"] > 0 and e2e["gather_s"] > 0
+    assert by_name["C4 prime64 N=16384 shard-resident"]["n_gpus"] == 2
