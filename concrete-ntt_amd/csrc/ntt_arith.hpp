@@ -61,59 +61,58 @@ __device__ __forceinline__ uint64_t mulhi(uint64_t a, uint64_t b) {
 
 // low B bits of a*b + c*d (wrapping)
 __device__ __forceinline__ uint32_t mullo2(uint32_t a, uint32_t b, uint32_t c, uint32_t d) { return a * b + c * d; }
-#ifndef CNTT_MULLO2_MODE
-#define CNTT_MULLO2_MODE 1
-#endif
-// acc.lo += a * b with the upper half of acc as scratch: ONE v_mad_u64_u32 instead of v_mul_lo_u32 + add.
-// (Plain C++ cannot express it: the compiler narrows a 64-bit accumulation whose upper half is dead.)
-__device__ __forceinline__ uint64_t mad_scratch_hi(uint32_t a, uint32_t b, uint64_t acc) {
-#if CNTT_MULLO2_MODE == 1
-    uint64_t r, carry;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(r), "=s"(carry) : "v"(a), "v"(b), "v"(acc));
-    return r;
-#else
-    uint64_t r = (uint64_t)a * b + acc;
-    asm("" : "+v"(r));
-    return r;
-#endif
-}
-__device__ __forceinline__ uint64_t mad_scratch_hi0(uint32_t a, uint32_t b) {
-#if CNTT_MULLO2_MODE == 1
-    uint64_t r, carry;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(r), "=s"(carry) : "v"(a), "v"(b));
-    return r;
-#else
-    uint64_t r = (uint64_t)a * b;
-    asm("" : "+v"(r));
-    return r;
-#endif
-}
-__device__ __forceinline__ uint64_t mullo2(uint64_t a, uint64_t b, uint64_t c, uint64_t d) {
-    const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32);
-    const uint32_t b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32);
-    const uint32_t c0 = (uint32_t)c, c1 = (uint32_t)(c >> 32);
-    const uint32_t d0 = (uint32_t)d, d1 = (uint32_t)(d >> 32);
-    uint64_t acc = (uint64_t)a0 * b0;
-    acc = (uint64_t)c0 * d0 + acc;  // wraps mod 2^64, which is what we want
-#if CNTT_MULLO2_MODE == 0
-    uint32_t hi = (uint32_t)(acc >> 32);
-    hi += a0 * b1 + a1 * b0 + c0 * d1 + c1 * d0;
-    return ((uint64_t)hi << 32) | (uint32_t)acc;
-#else
-    // the four cross products only matter modulo 2^32: accumulate them in the low word of a mad chain
-    uint64_t h = mad_scratch_hi0(a0, b1);
-    h = mad_scratch_hi(a1, b0, h);
-    h = mad_scratch_hi(c0, d1, h);
-    h = mad_scratch_hi(c1, d0, h);
-#if CNTT_MULLO2_MODE == 1
-    uint32_t hi;  // opaque add: otherwise the compiler folds h into the first product's addend at the price of two moves
-    asm("v_add_u32 %0, %1, %2" : "=v"(hi) : "v"((uint32_t)(acc >> 32)), "v"((uint32_t)h));
-#else
-    asm("" : "+v"(acc));
-    const uint32_t hi = (uint32_t)(acc >> 32) + (uint32_t)h;
-#endif
-    return ((uint64_t)hi << 32) | (uint32_t)acc;
-#endif
+
+// ---------------------------------------------------------------------------------------------
+// 64-bit Shoup product with an optional addend:
+//     shoup_core(y, w, ws, neg_p, x) = x + y*w + floor(y*ws / 2^64) * neg_p      (mod 2^64)
+// i.e. x + (y*w mod p) with the product left in [0, 2p) (any y < 2^64, w < p < 2^63, ws = floor(w 2^64 / p)),
+// in thirteen VALU instructions (ten multiplies).  The middle eight are one inline-asm block because two things
+// cannot be said in C++:
+//   * the carry of the cross-product sum y0*s1 + (y1*s0 + hi(y0*s0)) comes out of v_mad_u64_u32's own carry-out
+//     (v_mov + v_cndmask rebuild bits 32..95 of the sum instead of a three-instruction 96-bit add chain);
+//   * the four cross products of the low halves only matter modulo 2^32: they are accumulated in the LOW word of
+//     one v_mad_u64_u32 chain whose upper word is scratch (hipcc would narrow them to v_mul_lo_u32 + v_add).
+// The addend x rides in src2 of the low product y0*w0, so "x + t" costs nothing.  The quotient is handed back in
+// the fixed pair v[2:3]: VGPR tuples must be 64-bit aligned on gfx950 and the halves of a tuple cannot be named
+// through an asm operand, while the block has to address both halves (v_mov / v_cndmask, 32-bit multiplicands).
+// gfx950 needs two wait states between a VALU write of an SGPR and a VALU read of it: the v_cndmask sits three
+// instructions behind the v_mad that produces the carry.
+// UNI: w and ws are wave-uniform (SGPRs: first-pass twiddles, plan constants) -- one scalar source per
+// instruction, as the constant bus of this ISA allows.
+// ---------------------------------------------------------------------------------------------
+#define CNTT_SHOUP_BODY                                          \
+    "v_mad_u64_u32 v[2:3], %[c], %[y0], %[s1], %[u]\n\t"        \
+    "v_mad_u64_u32 %[h], vcc, %[y0], %[w1], 0\n\t"              \
+    "v_mad_u64_u32 %[h], vcc, %[y1], %[w0], %[h]\n\t"           \
+    "v_mov_b32 v2, v3\n\t"                                      \
+    "v_cndmask_b32_e64 v3, 0, 1, %[c]\n\t"                      \
+    "v_mad_u64_u32 v[2:3], vcc, %[y1], %[s1], v[2:3]\n\t"       \
+    "v_mad_u64_u32 %[h], vcc, v2, %[n1], %[h]\n\t"              \
+    "v_mad_u64_u32 %[h], vcc, v3, %[n0], %[h]"
+
+template <bool UNI, bool ADD>
+__device__ __forceinline__ uint64_t shoup_core(uint64_t y, uint64_t w, uint64_t ws, uint64_t neg_p, uint64_t x) {
+    const uint32_t y0 = (uint32_t)y, y1 = (uint32_t)(y >> 32);
+    const uint32_t s0 = (uint32_t)ws, s1 = (uint32_t)(ws >> 32);
+    const uint32_t w0 = (uint32_t)w, w1 = (uint32_t)(w >> 32);
+    const uint32_t n0 = (uint32_t)neg_p, n1 = (uint32_t)(neg_p >> 32);
+    const uint64_t t = __umulhi(y0, s0);
+    const uint64_t u = (uint64_t)y1 * s0 + t;  // cannot overflow
+    uint64_t q, h, carry;
+    if constexpr (UNI)
+        asm(CNTT_SHOUP_BODY : "={v[2:3]}"(q), [h] "=&v"(h), [c] "=&s"(carry)
+            : [y0] "v"(y0), [y1] "v"(y1), [s1] "s"(s1), [w0] "s"(w0), [w1] "s"(w1), [n0] "s"(n0), [n1] "s"(n1), [u] "v"(u)
+            : "vcc");
+    else
+        asm(CNTT_SHOUP_BODY : "={v[2:3]}"(q), [h] "=&v"(h), [c] "=&s"(carry)
+            : [y0] "v"(y0), [y1] "v"(y1), [s1] "v"(s1), [w0] "v"(w0), [w1] "v"(w1), [n0] "s"(n0), [n1] "s"(n1), [u] "v"(u)
+            : "vcc");
+    uint64_t acc = (uint64_t)y0 * w0;
+    if constexpr (ADD) acc += x;                      // one v_mad_u64_u32
+    uint32_t hi = (uint32_t)(acc >> 32) + (uint32_t)h;  // v_add_u32: the cross sum only reaches the upper word
+    asm("" : "+v"(hi));                               // (opaque, or hipcc turns it into a move and a 64-bit add)
+    acc = ((uint64_t)hi << 32) | (uint32_t)acc;
+    return (uint64_t)(uint32_t)q * n0 + acc;          // wraps modulo 2^64, as wanted
 }
 
 template <class T> __device__ __forceinline__ T umin(T a, T b) { return a < b ? a : b; }
@@ -132,9 +131,21 @@ template <class T> __device__ __forceinline__ T csub_two_p(T x, T two_p, T neg_t
 }
 
 // Shoup product: y * w - floor(y * ws / 2^B) * p, in [0, 2p) for any y < 2^B  (needs p < 2^(B-1))
-template <class T> __device__ __forceinline__ T shoup_mul(T y, T w, T ws, T neg_p) {
-    const T q = mulhi(y, ws);
-    return mullo2(y, w, q, neg_p);
+template <class T, bool UNI = false> __device__ __forceinline__ T shoup_mul(T y, T w, T ws, T neg_p) {
+    if constexpr (sizeof(T) == 8) {
+        return shoup_core<UNI, false>(y, w, ws, neg_p, 0);
+    } else {
+        const T q = mulhi(y, ws);
+        return mullo2(y, w, q, neg_p);
+    }
+}
+// x + shoup_mul(y, w, ws): for 64 bits the sum is free (the addend of the product's own multiply-add chain)
+template <class T, bool UNI = false> __device__ __forceinline__ T shoup_mad(T y, T w, T ws, T neg_p, T x) {
+    if constexpr (sizeof(T) == 8) {
+        return shoup_core<UNI, true>(y, w, ws, neg_p, x);
+    } else {
+        return x + shoup_mul<T>(y, w, ws, neg_p);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -170,16 +181,23 @@ template <class T> __device__ __forceinline__ T sub_mod(T a, T b, T p) {
 // butterflies
 // ---------------------------------------------------------------------------------------------
 template <class T, int CLS> struct Bfly {
-    // forward (Cooley-Tukey): (x, y) <- (x + w y, x - w y)
+    // forward (Cooley-Tukey): (x, y) <- (x + w y, x - w y).  UNI: w, ws are wave-uniform (scalar registers)
+    template <bool UNI = false>
     static __device__ __forceinline__ void fwd(T &x, T &y, T w, T ws, const ModParams<T> &P) {
         if constexpr (CLS == CLS_LAZY) {
             x = csub_two_p<T>(x, P.two_p, P.neg_two_p);
-            const T t = shoup_mul<T>(y, w, ws, P.neg_p);
-            y = (x + P.two_p) - t;
-            x = x + t;
+            if constexpr (sizeof(T) == 8) {
+                const T xn = shoup_mad<T, UNI>(y, w, ws, P.neg_p, x);  // x + t, t in [0, 2p)
+                y = ((x << 1) + P.two_p) - xn;                         // x - t + 2p
+                x = xn;
+            } else {
+                const T t = shoup_mul<T>(y, w, ws, P.neg_p);
+                y = (x + P.two_p) - t;
+                x = x + t;
+            }
         } else if constexpr (CLS == CLS_STRICT) {
             x = csub<T>(x, P.p);
-            const T t = csub<T>(shoup_mul<T>(y, w, ws, P.neg_p), P.p);
+            const T t = csub<T>(shoup_mul<T, UNI>(y, w, ws, P.neg_p), P.p);
             y = x - t + P.p;
             x = x + t;
         } else {
@@ -190,15 +208,16 @@ template <class T, int CLS> struct Bfly {
         }
     }
     // inverse (Gentleman-Sande): (x, y) <- (x + y, (x - y) w)
+    template <bool UNI = false>
     static __device__ __forceinline__ void inv(T &x, T &y, T w, T ws, const ModParams<T> &P) {
         if constexpr (CLS == CLS_LAZY) {
             const T d = (x + P.two_p) - y;
             x = csub_two_p<T>(x + y, P.two_p, P.neg_two_p);
-            y = shoup_mul<T>(d, w, ws, P.neg_p);
+            y = shoup_mul<T, UNI>(d, w, ws, P.neg_p);
         } else if constexpr (CLS == CLS_STRICT) {
             const T d = x - y + P.p;
             x = csub<T>(x + y, P.p);
-            y = csub<T>(shoup_mul<T>(d, w, ws, P.neg_p), P.p);
+            y = csub<T>(shoup_mul<T, UNI>(d, w, ws, P.neg_p), P.p);
         } else {
             const T x0 = x;
             x = add_mod<T>(x0, y, P.p);
@@ -209,11 +228,11 @@ template <class T, int CLS> struct Bfly {
     // w = inv_twid[1] for every butterfly of that stage, so P.last_w = w / N replaces the twiddle and only the
     // sum branch pays one extra product (N/2 per polynomial instead of the N of a separate normalize pass).
     static __device__ __forceinline__ void inv_norm(T &x, T &y, const ModParams<T> &P) {
-        inv(x, y, P.last_w, P.last_w_shoup, P);
+        inv<true>(x, y, P.last_w, P.last_w_shoup, P);
         if constexpr (CLS == CLS_LAZY) {
-            x = shoup_mul<T>(x, P.n_inv, P.n_inv_shoup, P.neg_p);  // [0, 2p)
+            x = shoup_mul<T, true>(x, P.n_inv, P.n_inv_shoup, P.neg_p);  // [0, 2p)
         } else if constexpr (CLS == CLS_STRICT) {
-            x = csub<T>(shoup_mul<T>(x, P.n_inv, P.n_inv_shoup, P.neg_p), P.p);
+            x = csub<T>(shoup_mul<T, true>(x, P.n_inv, P.n_inv_shoup, P.neg_p), P.p);
         } else {
             x = mont_mul(x, P.n_inv, P.p, P.pinv_neg);  // n_inv field = N^-1 R^2: x / R * (N^-1 R^2) / R ... see mul_for_inv
         }
@@ -266,7 +285,7 @@ template <class T> __device__ __forceinline__ T mul_normalize(T a, T b, const Mo
         return mont_mul(t, P.n_inv, P.p, P.pinv_neg);
     }
     const T prod = barrett_mul_lazy<T>(a, b, P);
-    const T t = prod * P.n_inv - mulhi(prod, P.n_inv_shoup) * P.p;
+    const T t = shoup_mul<T, true>(prod, P.n_inv, P.n_inv_shoup, P.neg_p);
     return csub<T>(t, P.p);
 }
 // a*b in the range the inverse butterflies of class CLS accept, WITHOUT the 1/N factor (Bfly::inv_norm applies it):
@@ -286,7 +305,7 @@ template <class T> __device__ __forceinline__ T normalize1(T a, const ModParams<
         const T t = mont_mul(a, P.n_inv, P.p, P.pinv_neg);
         return mont_mul(t, (T)1, P.p, P.pinv_neg);
     }
-    const T t = a * P.n_inv - mulhi(a, P.n_inv_shoup) * P.p;
+    const T t = shoup_mul<T, true>(a, P.n_inv, P.n_inv_shoup, P.neg_p);
     return csub<T>(t, P.p);
 }
 template <class T> __device__ __forceinline__ T mul_acc(T acc, T a, T b, const ModParams<T> &P, bool generic) {

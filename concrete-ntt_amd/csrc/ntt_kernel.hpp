@@ -168,6 +168,42 @@ struct NttKernel {
         }
     }
 
+    // ---- tile-relative global addressing (persistent kernels) -----------------------------------
+    // A tile's address is a workgroup-uniform base (an SGPR pair) plus ONE 32-bit byte offset per thread: the
+    // compiler selects global_load / global_store with an saddr operand, and no 64-bit per-thread pointers live in
+    // VGPRs across the butterflies.
+    template <uint32_t RM> static __device__ __forceinline__ void gather_tile(T (&r)[E], const T *tile, uint32_t voff) {
+        constexpr int NV = vec_elems<RM>();
+        using V = typename VecOf<T, NV>::type;
+#pragma unroll
+        for (int j = 0; j < E; j += NV) {
+            const uint32_t off = voff + cdep((uint32_t)j, RM) * (uint32_t)sizeof(T);
+            if constexpr (NV == 1) {
+                r[j] = *reinterpret_cast<const T *>(reinterpret_cast<const char *>(tile) + off);
+            } else {
+                const V v = *reinterpret_cast<const V *>(reinterpret_cast<const char *>(tile) + off);
+#pragma unroll
+                for (int i = 0; i < NV; ++i) r[j + i] = v[i];
+            }
+        }
+    }
+    template <uint32_t RM> static __device__ __forceinline__ void scatter_tile(const T (&r)[E], T *tile, uint32_t voff) {
+        constexpr int NV = vec_elems<RM>();
+        using V = typename VecOf<T, NV>::type;
+#pragma unroll
+        for (int j = 0; j < E; j += NV) {
+            const uint32_t off = voff + cdep((uint32_t)j, RM) * (uint32_t)sizeof(T);
+            if constexpr (NV == 1) {
+                *reinterpret_cast<T *>(reinterpret_cast<char *>(tile) + off) = r[j];
+            } else {
+                V v;
+#pragma unroll
+                for (int i = 0; i < NV; ++i) v[i] = r[j + i];
+                *reinterpret_cast<V *>(reinterpret_cast<char *>(tile) + off) = v;
+            }
+        }
+    }
+
     // ---- software-pipelined global loads (persistent kernel) ------------------------------------
     // hipcc keeps ONE in-order vmcnt model per loop and waits for freshly issued loads at the loop header,
     // so a prefetch written in plain C++ is waited for at once.  These loads are issued from inline asm
@@ -179,12 +215,31 @@ struct NttKernel {
     using AsyncVec = __attribute__((ext_vector_type(4))) uint32_t;
     template <uint32_t RM> static constexpr bool async_ok() { return vec_elems<RM>() == MAXV; }
 
-    template <uint32_t RM> static __device__ __forceinline__ void gather_async(AsyncVec (&v)[E / MAXV], const T *base, uint32_t ebase) {
-#pragma unroll
-        for (int j = 0; j < E; j += MAXV) {
-            const T *ptr = base + (ebase | cdep((uint32_t)j, RM));
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v[j / MAXV]) : "v"(ptr) : "memory");
+    // The loads use the saddr form (SGPR-pair tile base + 32-bit VGPR byte offset + 13-bit immediate): the per-vector
+    // element offsets cdep(j, RM) are compile-time constants and go into the instruction, one VGPR offset per 4 KiB
+    // window of the tile.
+    template <uint32_t RM, int JV = 0>
+    static __device__ __forceinline__ void gather_async_from(AsyncVec (&v)[E / MAXV], const T *tile, uint32_t woff, int window) {
+        if constexpr (JV < E / MAXV) {
+            constexpr uint32_t BYTE = cdep((uint32_t)(JV * MAXV), RM) * (uint32_t)sizeof(T);
+            constexpr int WIN = (int)(BYTE >> 12);
+            constexpr uint32_t IMM = BYTE & 4095u;
+            if (WIN == window)
+                asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(v[JV]) : "v"(woff), "s"(tile), "n"(IMM) : "memory");
+            gather_async_from<RM, JV + 1>(v, tile, woff, window);
         }
+    }
+    template <uint32_t RM> static constexpr int async_windows() {
+        int w = 0;
+        for (int jv = 0; jv < E / MAXV; ++jv) {
+            const int win = (int)((cdep((uint32_t)(jv * MAXV), RM) * (uint32_t)sizeof(T)) >> 12);
+            if (win > w) w = win;
+        }
+        return w + 1;
+    }
+    template <uint32_t RM> static __device__ __forceinline__ void gather_async(AsyncVec (&v)[E / MAXV], const T *tile, uint32_t voff) {
+#pragma unroll
+        for (int w = 0; w < async_windows<RM>(); ++w) gather_async_from<RM>(v, tile, voff + (uint32_t)w * 4096u, w);
     }
     // wait until at most YOUNGER vector-memory operations (issued after the async loads) are outstanding
     template <int YOUNGER> static __device__ __forceinline__ void wait_async(AsyncVec (&v)[E / MAXV]) {
@@ -323,10 +378,13 @@ struct NttKernel {
         for (int j = 0; j < E; ++j) {
             if ((j >> k) & 1) continue;
             const int h = j >> (k + 1);
+            // twiddles that do not depend on the thread come from scalar loads and stay in SGPRs (never for the
+            // sub-block kernels: their table prefix depends on the polynomial a thread works on)
+            constexpr bool UNI = geom(K, GI).uniform && !SUB && (LAB & 1) == 0;
             if constexpr (INV)
-                Bfly<T, CLS>::inv(r[j], r[j | (1 << k)], w[h].w, w[h].ws, P);
+                Bfly<T, CLS>::template inv<UNI>(r[j], r[j | (1 << k)], w[h].w, w[h].ws, P);
             else
-                Bfly<T, CLS>::fwd(r[j], r[j | (1 << k)], w[h].w, w[h].ws, P);
+                Bfly<T, CLS>::template fwd<UNI>(r[j], r[j | (1 << k)], w[h].w, w[h].ws, P);
         }
     }
 
@@ -464,22 +522,30 @@ struct NttWp : NttKernel<T, LOGN, INV, CLS, false, 0, FAM> {
         constexpr uint32_t CMIO = FULL & ~IO_RM;
         const uint32_t ebase0 = pdep<CM0>(tid), ebaseL = pdep<CML>(tid), ebaseIO = pdep<CMIO>(tid);
         const uint32_t ntiles = (nsub + PPB - 1) / PPB;
+        // byte offset of this thread's first vector inside a tile of PPB polynomials (IO layout)
+        const uint32_t voffIO = ((pl << LOGN) + ebaseIO) * (uint32_t)sizeof(T);
         T r[E];
 #pragma unroll
         for (int j = 0; j < E; ++j) r[j] = 0;
         uint32_t tile = blockIdx.x;
         if (tile < ntiles) {
             const uint32_t sub = tile * PPB + pl;
-            if (sub < nsub) B::template gather<IO_RM>(r, (const T *)(data + ((size_t)sub << LOGN)), ebaseIO, false);
+            if (sub < nsub) B::template gather_tile<IO_RM>(r, (const T *)(data + (((size_t)tile * PPB) << LOGN)), voffIO);
         }
         constexpr int NST = E / B::template vec_elems<IO_RM>();  // store instructions per tile (younger than the prefetch)
         for (; tile < ntiles; tile += gridDim.x) {
             const uint32_t sub = tile * PPB + pl;
-            uint32_t nxt = (tile + gridDim.x) * PPB + pl;
-            const bool more = (tile + gridDim.x) < ntiles;  // wave-uniform
-            if (nxt >= nsub) nxt = nsub - 1;                // ragged tail: harmless re-read of an in-range polynomial
+            const uint32_t tnext = tile + gridDim.x;
+            const bool more = tnext < ntiles;  // workgroup-uniform
+            T *tbase = data + (((size_t)tile * PPB) << LOGN);
             typename B::AsyncVec vn[E / B::MAXV];
-            if (more) B::template gather_async<IO_RM>(vn, (const T *)(data + ((size_t)nxt << LOGN)), ebaseIO);
+            if (more) {
+                // ragged tail: lanes of polynomials past the end re-read the last polynomial (harmless, in range)
+                const uint32_t last = nsub - 1u - tnext * PPB;
+                const uint32_t pln = pl < last ? pl : last;
+                B::template gather_async<IO_RM>(vn, (const T *)(data + (((size_t)tnext * PPB) << LOGN)),
+                                                ((pln << LOGN) + ebaseIO) * (uint32_t)sizeof(T));
+            }
             if constexpr (RM0 != IO_RM) {  // input transpose
                 B::template scatter<IO_RM>(r, lds, ebaseIO, true);
                 wsync();
@@ -493,7 +559,7 @@ struct NttWp : NttKernel<T, LOGN, INV, CLS, false, 0, FAM> {
                 wsync();
                 B::template gather<IO_RM>(r, (const T *)lds, ebaseIO, true);
             }
-            if (sub < nsub) B::template scatter<IO_RM>(r, data + ((size_t)sub << LOGN), ebaseIO, false);
+            if (sub < nsub) B::template scatter_tile<IO_RM>(r, tbase, voffIO);
             wsync();  // the exchange buffer is reused by the next tile
             if (more) {
                 // lanes of inactive polynomials skipped their stores: the counter then allows fewer
@@ -548,23 +614,28 @@ struct MulWp {
         constexpr uint32_t CM0 = FULL & ~RM0, CMM = FULL & ~RMM, CML = FULL & ~RML, CMIO = FULL & ~IO_RM;
         const uint32_t ebase0 = pdep<CM0>(tid), ebaseM = pdep<CMM>(tid), ebaseL = pdep<CML>(tid), ebaseIO = pdep<CMIO>(tid);
         const uint32_t ntiles = (nsub + PPB - 1) / PPB;
+        const uint32_t voffIO = ((pl << LOGN) + ebaseIO) * (uint32_t)sizeof(T);
         T r[E];
 #pragma unroll
         for (int j = 0; j < E; ++j) r[j] = 0;
         uint32_t tile = blockIdx.x;
         if (tile < ntiles) {
             const uint32_t sub = tile * PPB + pl;
-            if (sub < nsub) FB::template gather<IO_RM>(r, (const T *)(lhs + ((size_t)sub << LOGN)), ebaseIO, false);
+            if (sub < nsub) FB::template gather_tile<IO_RM>(r, (const T *)(lhs + (((size_t)tile * PPB) << LOGN)), voffIO);
         }
         constexpr int NST = E / FB::template vec_elems<IO_RM>();
         for (; tile < ntiles; tile += gridDim.x) {
             const uint32_t sub = tile * PPB + pl;
-            const uint32_t subc = sub < nsub ? sub : nsub - 1;  // clamped index for the reads of a ragged tail
-            uint32_t nxt = (tile + gridDim.x) * PPB + pl;
-            const bool more = (tile + gridDim.x) < ntiles;
-            if (nxt >= nsub) nxt = nsub - 1;
+            const uint32_t tnext = tile + gridDim.x;
+            const bool more = tnext < ntiles;
+            T *tbase = lhs + (((size_t)tile * PPB) << LOGN);
             typename FB::AsyncVec vn[E / FB::MAXV];
-            if (more) FB::template gather_async<IO_RM>(vn, (const T *)(lhs + ((size_t)nxt << LOGN)), ebaseIO);
+            if (more) {
+                const uint32_t last = nsub - 1u - tnext * PPB;
+                const uint32_t pln = pl < last ? pl : last;
+                FB::template gather_async<IO_RM>(vn, (const T *)(lhs + (((size_t)tnext * PPB) << LOGN)),
+                                                 ((pln << LOGN) + ebaseIO) * (uint32_t)sizeof(T));
+            }
             if constexpr (RM0 != IO_RM) {
                 FB::template scatter<IO_RM>(r, lds, ebaseIO, true);
                 F::wsync();
@@ -573,8 +644,12 @@ struct MulWp {
             }
             F::template pass<0>(r, lds, tid, twf, imgf, P);  // canonical NTT-domain values, layout RMM
             {
+                // clamped polynomial index for the reads of a ragged tail
+                const uint32_t lastc = nsub - 1u - tile * PPB;
+                const uint32_t plc = pl < lastc ? pl : lastc;
                 T b[E];
-                FB::template gather<RMM>(b, rhs_ntt + ((size_t)subc << LOGN), ebaseM, false);
+                FB::template gather_tile<RMM>(b, rhs_ntt + (((size_t)tile * PPB) << LOGN),
+                                              ((plc << LOGN) + ebaseM) * (uint32_t)sizeof(T));
 #pragma unroll
                 for (int j = 0; j < E; ++j) r[j] = mul_for_inv<T, CLS>(r[j], b[j], P);  // 1/N: inside the last inverse stage
             }
@@ -586,7 +661,7 @@ struct MulWp {
                 F::wsync();
                 FB::template gather<IO_RM>(r, (const T *)lds, ebaseIO, true);
             }
-            if (sub < nsub) FB::template scatter<IO_RM>(r, lhs + ((size_t)sub << LOGN), ebaseIO, false);
+            if (sub < nsub) FB::template scatter_tile<IO_RM>(r, tbase, voffIO);
             F::wsync();
             if (more) {
                 FB::template wait_async<NST>(vn);
