@@ -63,6 +63,8 @@ static inline unsigned ew_grid(size_t work_items) {
 // ---------------------------------------------------------------------------------------------
 template <class T> struct DeviceTables {
     TwPair<T> *fwd = nullptr, *inv = nullptr;
+    // CLS_FP plans only: the same twiddles as (c, c / p) doubles, c centred in (-p/2, p/2]
+    TwPair<T> *fwd_fp = nullptr, *inv_fp = nullptr;
 };
 
 template <class T> struct DeviceCache {
@@ -75,6 +77,8 @@ template <class T> struct DeviceCache {
             (void)hipSetDevice(kv.first);
             (void)hipFree(kv.second.fwd);
             (void)hipFree(kv.second.inv);
+            (void)hipFree(kv.second.fwd_fp);
+            (void)hipFree(kv.second.inv_fp);
             (void)hipSetDevice(cur);
         }
     }
@@ -183,9 +187,31 @@ template <class T, class PlanT> static int plan_new(size_t n, T p, PlanT **out) 
         mp.last_w = (T)w_last;
         mp.last_w_shoup = shoup_of<T>((T)w_last, p);
     }
+    // CLS_FP: 64-bit words, p < 2^50 (src/prime64/less_than_50bit.rs's class).  CNTT_DISABLE_FP=1 keeps such plans on the
+    // integer butterflies (A/B measurements, and tests that compare the two paths).
+    mp.fp = 0;
+    if constexpr (B == 64) {
+        const char *off = std::getenv("CNTT_DISABLE_FP");
+        if (p64 < ((uint64_t)1 << 50) && !(off && off[0] == '1')) {
+            mp.fp = 1;
+            const double pd = (double)p64;
+            mp.fp_p = host::double_bits(pd);
+            mp.fp_pinv = host::double_bits(1.0 / pd);
+            const double ni = host::centred(pl->n_inv, p64), wl = host::centred(w_last, p64);
+            mp.fp_n_inv = host::double_bits(ni);
+            mp.fp_n_inv_q = host::double_bits(ni / pd);
+            mp.fp_last_w = host::double_bits(wl);
+            mp.fp_last_w_q = host::double_bits(wl / pd);
+        }
+    }
     pl->cache = std::make_shared<DeviceCache<T>>();
     *out = pl;
     return CNTT_OK;
+}
+
+// transform class of the LDS-resident kernels for this plan (the global-stage path of larger sizes is integer-only)
+template <class T> static int transform_class(const PrimePlan<T> *pl) {
+    return (pl->mp.fp && pl->logn <= MaxLdsLogN<T>::value) ? (int)CLS_FP : (int)pl->mp.cls;
 }
 
 // per-device table replica, created on first use under the cache mutex
@@ -223,6 +249,27 @@ template <class T> static int device_tables(const PrimePlan<T> *pl, DeviceTables
     }
     HIP_TRY(hipMemcpy(t.fwd, f.data(), n * sizeof(TwPair<T>), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(t.inv, i.data(), n * sizeof(TwPair<T>), hipMemcpyHostToDevice));
+    if constexpr (sizeof(T) == 8) {
+        if (pl->mp.fp) {
+            const double pd = (double)p64;
+            for (size_t k = 0; k < n; ++k) {
+                const double cf = host::centred((uint64_t)pl->twid[k], p64), ci = host::centred((uint64_t)pl->inv_twid[k], p64);
+                f[k].w = host::double_bits(cf);
+                f[k].ws = host::double_bits(cf / pd);
+                i[k].w = host::double_bits(ci);
+                i[k].ws = host::double_bits(ci / pd);
+            }
+            if (hipMalloc((void **)&t.fwd_fp, n * sizeof(TwPair<T>)) != hipSuccess ||
+                hipMalloc((void **)&t.inv_fp, n * sizeof(TwPair<T>)) != hipSuccess) {
+                (void)hipFree(t.fwd);
+                (void)hipFree(t.inv);
+                (void)hipFree(t.fwd_fp);
+                return fail(CNTT_ENOMEM, "hipMalloc of the twiddle tables failed");
+            }
+            HIP_TRY(hipMemcpy(t.fwd_fp, f.data(), n * sizeof(TwPair<T>), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(t.inv_fp, i.data(), n * sizeof(TwPair<T>), hipMemcpyHostToDevice));
+        }
+    }
     pl->cache->per_device[dev] = t;
     *out = t;
     return CNTT_OK;
@@ -255,12 +302,13 @@ template <class T> static int ntt_device(const PrimePlan<T> *pl, T *d, size_t ba
     if ((batch << depth) >= ((size_t)1 << 32)) return fail(CNTT_EINVAL, "batch too large for one launch");
     const uint32_t nsub = (uint32_t)(batch << depth);
     const size_t nbfly = batch * (pl->n / 2);
+    const int tcls = transform_class(pl);
     hipError_t e;
     if (!inv) {
         for (int s = 0; s < depth; ++s) global_stage<T, false>(d, t.fwd, pl->mp, (uint32_t)pl->logn, (uint32_t)s, nbfly, false, st);
-        e = launch_ntt<T, false>(sub_logn, (int)pl->mp.cls, d, t.fwd, pl->mp, nsub, (uint32_t)depth, st);
+        e = launch_ntt<T, false>(sub_logn, tcls, d, tcls == CLS_FP ? t.fwd_fp : t.fwd, pl->mp, nsub, (uint32_t)depth, st);
     } else {
-        e = launch_ntt<T, true>(sub_logn, (int)pl->mp.cls, d, t.inv, pl->mp, nsub, (uint32_t)depth, st);
+        e = launch_ntt<T, true>(sub_logn, tcls, d, tcls == CLS_FP ? t.inv_fp : t.inv, pl->mp, nsub, (uint32_t)depth, st);
         for (int s = depth - 1; s >= 0 && e == hipSuccess; --s)
             global_stage<T, true>(d, t.inv, pl->mp, (uint32_t)pl->logn, (uint32_t)s, nbfly, s == 0, st);
     }
@@ -299,7 +347,9 @@ template <class T> static int mul_ntt_device(const PrimePlan<T> *pl, T *lhs, con
     if (batch >= ((size_t)1 << 32)) return fail(CNTT_EINVAL, "batch too large for one launch");
     DeviceTables<T> t;
     if (int rc = device_tables(pl, &t)) return rc;
-    const hipError_t e = launch_mul_ntt<T>(pl->logn, (int)pl->mp.cls, lhs, rhs, t.fwd, t.inv, pl->mp, (uint32_t)batch, st);
+    const int tcls = transform_class(pl);
+    const hipError_t e = launch_mul_ntt<T>(pl->logn, tcls, lhs, rhs, tcls == CLS_FP ? t.fwd_fp : t.fwd,
+                                           tcls == CLS_FP ? t.inv_fp : t.inv, pl->mp, (uint32_t)batch, st);
     if (e == hipSuccess) return CNTT_OK;
     if (e != hipErrorNotSupported) return fail(CNTT_EDEVICE, "fused product launch failed: %s", hipGetErrorString(e));
     (void)hipGetLastError();
@@ -323,8 +373,10 @@ static int external_product_device(const PrimePlan<T> *pl, T *out, const T *term
     }
     DeviceTables<T> t;
     if (int rc = device_tables(pl, &t)) return rc;
-    const hipError_t e = launch_ext_ntt<T>(pl->logn, (int)pl->mp.cls, out, terms, key, t.fwd, t.inv, pl->mp, (uint32_t)batch,
-                                           (uint32_t)nterms, (uint32_t)nout, accumulate, st);
+    const int tcls = transform_class(pl);
+    const hipError_t e = launch_ext_ntt<T>(pl->logn, tcls, out, terms, key, tcls == CLS_FP ? t.fwd_fp : t.fwd,
+                                           tcls == CLS_FP ? t.inv_fp : t.inv, pl->mp, (uint32_t)batch, (uint32_t)nterms,
+                                           (uint32_t)nout, accumulate, st);
     if (e == hipSuccess) return CNTT_OK;
     if (e != hipErrorNotSupported) return fail(CNTT_EDEVICE, "fused mul_accumulate chain launch failed: %s", hipGetErrorString(e));
     (void)hipGetLastError();
@@ -420,7 +472,7 @@ template <class T> static int plan_info(const PrimePlan<T> *pl, cntt_plan_info_t
     out->n_inv_mod_p_shoup = pl->n_inv_shoup;
     out->root = pl->root;
     out->has_shoup = pl->has_shoup ? 1 : 0;
-    out->arith_class = (int32_t)pl->mp.cls;
+    out->arith_class = (int32_t)transform_class(pl);
     return CNTT_OK;
 }
 template <class T> static int plan_table(const PrimePlan<T> *pl, cntt_table_t which, T *out, size_t len) {

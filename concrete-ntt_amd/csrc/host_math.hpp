@@ -130,5 +130,14 @@ inline uint64_t neg_inv_pow2(uint64_t x) {
     return (uint64_t)0 - inv;
 }
 
+// CLS_FP table entries: the centred representative of x mod p as an exact double (p < 2^50), and a double's bits
+inline double centred(uint64_t x, uint64_t p) { return x > p / 2 ? -(double)(p - x) : (double)x; }
+inline uint64_t double_bits(double d) {
+    uint64_t u;
+    static_assert(sizeof u == sizeof d, "IEEE double");
+    __builtin_memcpy(&u, &d, sizeof u);
+    return u;
+}
+
 }  // namespace host
 }  // namespace cntt

@@ -10,13 +10,18 @@
 //   CLS_GENERIC any p (used for p >= 2^(B-1), incl. Solinas): canonical values, Montgomery
 //               products against twiddles stored in Montgomery form.  The reference does exact
 //               `%`-products there (src/prime64/generic_solinas.rs:42-128): same values.
+//   CLS_FP      64-bit words, p < 2^50 (the reference's src/prime64/less_than_50bit.rs class, and every Plan52
+//               native plan): the LDS-resident transforms keep each residue as an IEEE double holding an exact
+//               integer representative |v| < 2^53 and multiply with v_fma_f64 -- on gfx950 a double FMA
+//               issues at the rate of ONE 32-bit integer multiply, and an exact 50 x 53-bit modular product
+//               is six of them instead of ten integer multiplies and their carry chains (see Bfly<T, CLS_FP>).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace cntt {
 
-enum : int { CLS_LAZY = 0, CLS_STRICT = 1, CLS_GENERIC = 2 };
+enum : int { CLS_LAZY = 0, CLS_STRICT = 1, CLS_GENERIC = 2, CLS_FP = 3 };
 
 // One table entry: the twiddle and its Shoup companion floor(w * 2^B / p) (CLS_GENERIC: w holds
 // w * 2^B mod p and ws is unused).  Interleaved so that one 16-byte (u64) / 8-byte (u32) load
@@ -37,8 +42,12 @@ template <class T> struct ModParams {
     T r2;                  // 2^(2B) mod p (GENERIC pointwise)
     T last_w, last_w_shoup; // inv_twid[1] * N^-1 mod p and its Shoup companion (GENERIC: * 2^(2B), unused): the
                            // fused product kernel normalises inside the last inverse stage (Bfly::inv_norm)
+    // CLS_FP (64-bit words, p < 2^50): bit patterns of doubles -- p, 1/p, and the plan constants in centred
+    // form c in (-p/2, p/2] with their quotient companions c/p
+    T fp_p, fp_pinv, fp_n_inv, fp_n_inv_q, fp_last_w, fp_last_w_q;
     uint32_t big_q;        // floor(log2 p) + 1
-    uint32_t cls;
+    uint32_t cls;          // integer arithmetic class (pointwise kernels, global stages, every non-FP transform)
+    uint32_t fp;           // 1: the LDS-resident transforms of this plan run in CLS_FP
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -100,11 +109,11 @@ __device__ __forceinline__ uint64_t shoup_core(uint64_t y, uint64_t w, uint64_t 
     const uint64_t u = (uint64_t)y1 * s0 + t;  // cannot overflow
     uint64_t q, h, carry;
     if constexpr (UNI)
-        asm(CNTT_SHOUP_BODY : "={v[2:3]}"(q), [h] "=&v"(h), [c] "=&s"(carry)
+        asm(CNTT_SHOUP_BODY : "=&{v[2:3]}"(q), [h] "=&v"(h), [c] "=&s"(carry)
             : [y0] "v"(y0), [y1] "v"(y1), [s1] "s"(s1), [w0] "s"(w0), [w1] "s"(w1), [n0] "s"(n0), [n1] "s"(n1), [u] "v"(u)
             : "vcc");
     else
-        asm(CNTT_SHOUP_BODY : "={v[2:3]}"(q), [h] "=&v"(h), [c] "=&s"(carry)
+        asm(CNTT_SHOUP_BODY : "=&{v[2:3]}"(q), [h] "=&v"(h), [c] "=&s"(carry)
             : [y0] "v"(y0), [y1] "v"(y1), [s1] "v"(s1), [w0] "v"(w0), [w1] "v"(w1), [n0] "s"(n0), [n1] "s"(n1), [u] "v"(u)
             : "vcc");
     uint64_t acc = (uint64_t)y0 * w0;
@@ -237,6 +246,9 @@ template <class T, int CLS> struct Bfly {
             x = mont_mul(x, P.n_inv, P.p, P.pinv_neg);  // n_inv field = N^-1 R^2: x / R * (N^-1 R^2) / R ... see mul_for_inv
         }
     }
+    // a word as loaded from memory -> the class's register form (identity for the integer classes)
+    static __device__ __forceinline__ T load_fix(T v) { return v; }
+    static __device__ __forceinline__ T reduce(T v, const ModParams<T> &) { return v; }
     // bring a value left by the last stage into [0, p)
     static __device__ __forceinline__ T finish_fwd(T v, const ModParams<T> &P) {
         if constexpr (CLS == CLS_LAZY) return csub<T>(csub_two_p<T>(v, P.two_p, P.neg_two_p), P.p);
@@ -247,6 +259,89 @@ template <class T, int CLS> struct Bfly {
         if constexpr (CLS == CLS_LAZY) return csub<T>(v, P.p);
         return v;
     }
+};
+
+// ---------------------------------------------------------------------------------------------
+// CLS_FP: residues as exact integers in doubles (64-bit words, p < 2^50)
+//
+// A register holds the bit pattern of a double v, an exact integer with v = residue (mod p) and |v| < 2^53.
+// Product by a table constant c (centred, |c| <= p/2) with its companion cq = fl(c / p):
+//     h = fl(y c)   l = fma(y, c, -h) (exact error term)   q = rint(fl(y cq))   r = fma(-q, p, h) (exact)   t = r + l
+// y c - q p = t exactly, and |q - y c / p| <= 1/2 + |y| 2^-53, so |t| <= (1/2 + |y| 2^-53) p; h - q p = t - l is an
+// integer below 2^53 because |l| <= ulp(h)/2 <= |y| p 2^-54.  Every sum x +- t is exact while it stays below 2^53 >
+// 8p, which the kernels guarantee by a range reduction v - p rint(v / p) (three instructions) every few stages:
+//     forward  (x, y) <- (x + t, x - t): the bound grows by <= (1/2 + B 2^-53) p per stage: from p (canonical input)
+//              1.63p, 2.33p, 3.12p, 4.01p, 5.01p; from p/2 (after a reduction) 1.06p ... 4.11p -> reduce every fifth stage;
+//     inverse  (x, y) <- (x + y, (x - y) w): sums double, products come back below p (|x - y| <= 4p): inputs <= p give
+//              2p, then 4p -> the sums are reduced after every second stage, so |x - y| <= 4p and |x + y| <= 4p always.
+// Twiddles come from a table of (c, c/p) doubles built by the host (csrc/host.hip); the public values are the same
+// canonical integers as in every other class: the load turns a canonical word into a double (two instructions) and
+// the store reduces, lifts negatives by p and extracts the integer (nine).
+// ---------------------------------------------------------------------------------------------
+struct Fp {
+    static __device__ __forceinline__ double d(uint64_t v) { return __longlong_as_double((long long)v); }
+    static __device__ __forceinline__ uint64_t u(double x) { return (uint64_t)__double_as_longlong(x); }
+    // canonical word (< 2^52) -> double: 2^52 + v is the double whose mantissa field is v
+    static __device__ __forceinline__ double from_word(uint64_t v) {
+        return __dadd_rn(d(v | 0x4330000000000000ull), -4503599627370496.0);
+    }
+    // v - p rint(v / p): |result| <= (1/2 + 2^-49) p for |v| < 2^53
+    static __device__ __forceinline__ double reduce(double v, double p, double pinv) {
+        const double q = __builtin_rint(__dmul_rn(v, pinv));
+        return __fma_rn(-q, p, v);
+    }
+    // y * c mod p for a table constant (c, cq = c / p)
+    static __device__ __forceinline__ double mul_const(double y, double c, double cq, double p) {
+        const double h = __dmul_rn(y, c);
+        const double q = __builtin_rint(__dmul_rn(y, cq));
+        const double l = __fma_rn(y, c, -h);
+        const double r = __fma_rn(-q, p, h);
+        return __dadd_rn(r, l);
+    }
+    // a * b mod p for two data values, |a|, |b| <= p: |result| <= 0.7 p
+    static __device__ __forceinline__ double mul_data(double a, double b, double p, double pinv) {
+        const double h = __dmul_rn(a, b);
+        const double q = __builtin_rint(__dmul_rn(h, pinv));
+        const double l = __fma_rn(a, b, -h);
+        const double r = __fma_rn(-q, p, h);
+        return __dadd_rn(r, l);
+    }
+    // |v| < 2^53 -> canonical word in [0, p)
+    static __device__ __forceinline__ uint64_t to_word(double v, double p, double pinv) {
+        double r = reduce(v, p, pinv);                    // |r| <= p/2 (+1)
+        r = r < 0.0 ? __dadd_rn(r, p) : r;                // [0, p)
+        return u(__dadd_rn(r, 4503599627370496.0)) & 0x000fffffffffffffull;  // mantissa field of 2^52 + r
+    }
+};
+
+template <class T> struct Bfly<T, CLS_FP> {
+    static_assert(sizeof(T) == 8, "CLS_FP is a 64-bit class");
+    static __device__ __forceinline__ T load_fix(T v) { return Fp::u(Fp::from_word(v)); }
+    static __device__ __forceinline__ T reduce(T v, const ModParams<T> &P) {
+        return Fp::u(Fp::reduce(Fp::d(v), Fp::d(P.fp_p), Fp::d(P.fp_pinv)));
+    }
+    template <bool UNI = false>
+    static __device__ __forceinline__ void fwd(T &x, T &y, T w, T ws, const ModParams<T> &P) {
+        const double t = Fp::mul_const(Fp::d(y), Fp::d(w), Fp::d(ws), Fp::d(P.fp_p));
+        const double xd = Fp::d(x);
+        x = Fp::u(__dadd_rn(xd, t));
+        y = Fp::u(__dadd_rn(xd, -t));
+    }
+    template <bool UNI = false>
+    static __device__ __forceinline__ void inv(T &x, T &y, T w, T ws, const ModParams<T> &P) {
+        const double xd = Fp::d(x), yd = Fp::d(y);
+        x = Fp::u(__dadd_rn(xd, yd));
+        y = Fp::u(Fp::mul_const(__dadd_rn(xd, -yd), Fp::d(w), Fp::d(ws), Fp::d(P.fp_p)));
+    }
+    static __device__ __forceinline__ void inv_norm(T &x, T &y, const ModParams<T> &P) {
+        const double xd = Fp::d(x), yd = Fp::d(y), p = Fp::d(P.fp_p);
+        x = Fp::u(Fp::mul_const(__dadd_rn(xd, yd), Fp::d(P.fp_n_inv), Fp::d(P.fp_n_inv_q), p));
+        y = Fp::u(Fp::mul_const(__dadd_rn(xd, -yd), Fp::d(P.fp_last_w), Fp::d(P.fp_last_w_q), p));
+    }
+    static __device__ __forceinline__ T finish_fwd(T v, const ModParams<T> &P) {
+        return Fp::to_word(Fp::d(v), Fp::d(P.fp_p), Fp::d(P.fp_pinv));
+    }
+    static __device__ __forceinline__ T finish_inv(T v, const ModParams<T> &P) { return finish_fwd(v, P); }
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -291,7 +386,11 @@ template <class T> __device__ __forceinline__ T mul_normalize(T a, T b, const Mo
 // a*b in the range the inverse butterflies of class CLS accept, WITHOUT the 1/N factor (Bfly::inv_norm applies it):
 // LAZY [0, 2p); STRICT canonical; GENERIC a b / R canonical (inv_norm's constants carry the R^2).
 template <class T, int CLS> __device__ __forceinline__ T mul_for_inv(T a, T b, const ModParams<T> &P) {
-    if constexpr (CLS == CLS_GENERIC) {
+    if constexpr (CLS == CLS_FP) {
+        // a: the forward transform's lazy double (|a| < 8p), b: a canonical word from memory; result |.| <= 0.7 p
+        const double p = Fp::d(P.fp_p), pinv = Fp::d(P.fp_pinv);
+        return Fp::u(Fp::mul_data(Fp::reduce(Fp::d(a), p, pinv), Fp::from_word(b), p, pinv));
+    } else if constexpr (CLS == CLS_GENERIC) {
         return mont_mul(a, b, P.p, P.pinv_neg);
     } else if constexpr (CLS == CLS_STRICT) {
         return csub<T>(barrett_mul_lazy<T>(a, b, P), P.p);
@@ -317,6 +416,17 @@ template <class T> __device__ __forceinline__ T mul_acc(T acc, T a, T b, const M
     T prod = barrett_mul_lazy<T>(a, b, P);
     prod = csub<T>(prod, P.p);
     return csub<T>(prod + acc, P.p);
+}
+
+// acc + a * b in the accumulator form of class CLS (the fused mul_accumulate chains): the integer classes keep
+// canonical accumulators; CLS_FP adds the product (|.| <= 0.7 p, `a` already range-reduced) to a lazy double.
+template <class T, int CLS> __device__ __forceinline__ T mul_acc_cls(T acc, T a, T b, const ModParams<T> &P) {
+    if constexpr (CLS == CLS_FP) {
+        const double p = Fp::d(P.fp_p), pinv = Fp::d(P.fp_pinv);
+        return Fp::u(__dadd_rn(Fp::d(acc), Fp::mul_data(Fp::d(a), Fp::from_word(b), p, pinv)));
+    } else {
+        return mul_acc<T>(acc, a, b, P, CLS == CLS_GENERIC);
+    }
 }
 
 }  // namespace cntt

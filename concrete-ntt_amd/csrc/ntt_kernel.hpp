@@ -313,6 +313,12 @@ struct NttKernel {
         return off;
     }
     static constexpr int IMG_ENTRIES = img_off(NPASS, 0) > 0 ? img_off(NPASS, 0) : 1;
+    // number of butterfly stages of the transform that precede stage (K, GI)
+    static constexpr int stage_no(int K, int GI) {
+        int n = GI;
+        for (int kk = 0; kk < K; ++kk) n += cpop(S::GMASK[kk]);
+        return n;
+    }
 
     template <int K, int GI>
     static __device__ __forceinline__ void fill_image_stage(TwPair<T> *img, const TwPair<T> *__restrict__ tw) {
@@ -386,6 +392,21 @@ struct NttKernel {
             else
                 Bfly<T, CLS>::template fwd<UNI>(r[j], r[j | (1 << k)], w[h].w, w[h].ws, P);
         }
+        if constexpr (CLS == CLS_FP) {
+            // range reductions of the double-held residues (bounds: Bfly<T, CLS_FP>): forward, every value after every
+            // fifth stage; inverse, the sums after every second stage.  The last stage is followed by finish_*.
+            static_assert(!SUB, "CLS_FP covers whole LDS-resident transforms only");
+            constexpr int SNO = stage_no(K, GI);
+            if constexpr (!INV && SNO % 5 == 4 && SNO != LOGN - 1) {
+#pragma unroll
+                for (int j = 0; j < E; ++j) r[j] = Bfly<T, CLS>::reduce(r[j], P);
+            }
+            if constexpr (INV && SNO % 2 == 1 && SNO != LOGN - 1) {
+#pragma unroll
+                for (int j = 0; j < E; ++j)
+                    if (((j >> k) & 1) == 0) r[j] = Bfly<T, CLS>::reduce(r[j], P);
+            }
+        }
     }
 
     template <int K, int GI = 0, bool IMG = false, bool NORM = false>
@@ -407,6 +428,8 @@ struct NttKernel {
         if constexpr (K == 0) {
             if constexpr ((LAB & 4) == 0) {
                 if (active) gather<RM>(r, (const T *)g, ebase, false);
+#pragma unroll
+                for (int j = 0; j < E; ++j) r[j] = Bfly<T, CLS>::load_fix(r[j]);
             }
         } else if constexpr ((LAB & 2) == 0) {
             gather<RM>(r, (const T *)lds, ebase, true);
@@ -484,7 +507,9 @@ struct NttWp : NttKernel<T, LOGN, INV, CLS, false, 0, FAM> {
 
     // IMG: thread-dependent twiddles come from the workgroup's LDS image (fill_image); otherwise from the table in
     // global memory (L2), for kernels that walk several primes and cannot hold an image per prime
-    template <int K, bool NORM = false, bool IMG = true>
+    // FIN: bring the outputs into [0, p) (what memory holds); fused kernels whose next step takes the class's lazy
+    // register form (CLS_FP products) skip it
+    template <int K, bool NORM = false, bool IMG = true, bool FIN = true>
     static __device__ __forceinline__ void pass(T (&r)[E], T *lds, uint32_t tid, const TwPair<T> *__restrict__ tw,
                                                 const TwPair<T> *img, const ModParams<T> &P) {
         constexpr uint32_t RM = S::RMASK[K], CM = FULL & ~RM;
@@ -495,8 +520,8 @@ struct NttWp : NttKernel<T, LOGN, INV, CLS, false, 0, FAM> {
             if constexpr (K > 0) wsync();
             B::template scatter<RM>(r, lds, ebase, true);
             wsync();
-            pass<K + 1, NORM, IMG>(r, lds, tid, tw, img, P);
-        } else {
+            pass<K + 1, NORM, IMG, FIN>(r, lds, tid, tw, img, P);
+        } else if constexpr (FIN) {
 #pragma unroll
             for (int j = 0; j < E; ++j) r[j] = INV ? Bfly<T, CLS>::finish_inv(r[j], P) : Bfly<T, CLS>::finish_fwd(r[j], P);
         }
@@ -546,6 +571,8 @@ struct NttWp : NttKernel<T, LOGN, INV, CLS, false, 0, FAM> {
                 B::template gather_async<IO_RM>(vn, (const T *)(data + (((size_t)tnext * PPB) << LOGN)),
                                                 ((pln << LOGN) + ebaseIO) * (uint32_t)sizeof(T));
             }
+#pragma unroll
+            for (int j = 0; j < E; ++j) r[j] = Bfly<T, CLS>::load_fix(r[j]);  // memory word -> register form
             if constexpr (RM0 != IO_RM) {  // input transpose
                 B::template scatter<IO_RM>(r, lds, ebaseIO, true);
                 wsync();
@@ -636,13 +663,16 @@ struct MulWp {
                 FB::template gather_async<IO_RM>(vn, (const T *)(lhs + (((size_t)tnext * PPB) << LOGN)),
                                                  ((pln << LOGN) + ebaseIO) * (uint32_t)sizeof(T));
             }
+#pragma unroll
+            for (int j = 0; j < E; ++j) r[j] = Bfly<T, CLS>::load_fix(r[j]);
             if constexpr (RM0 != IO_RM) {
                 FB::template scatter<IO_RM>(r, lds, ebaseIO, true);
                 F::wsync();
                 FB::template gather<RM0>(r, (const T *)lds, ebase0, true);
                 F::wsync();
             }
-            F::template pass<0>(r, lds, tid, twf, imgf, P);  // canonical NTT-domain values, layout RMM
+            // NTT-domain values in layout RMM: canonical, or (CLS_FP) the lazy doubles mul_for_inv takes
+            F::template pass<0, false, true, CLS != CLS_FP>(r, lds, tid, twf, imgf, P);
             {
                 // clamped polynomial index for the reads of a ragged tail
                 const uint32_t lastc = nsub - 1u - tile * PPB;
@@ -718,16 +748,15 @@ struct ExtWp {
                                                        uint32_t ebase, const ModParams<T> &P) {
         constexpr int NV = FB::template vec_elems<RMM>();
         using V = typename VecOf<T, NV>::type;
-        const bool generic = CLS == CLS_GENERIC;
 #pragma unroll
         for (int j = 0; j < E; j += NV) {
             const uint32_t e = ebase | cdep((uint32_t)j, RMM);
             if constexpr (NV == 1) {
-                acc[j] = mul_acc<T>(acc[j], r[j], key[e], P, generic);
+                acc[j] = mul_acc_cls<T, CLS>(acc[j], r[j], key[e], P);
             } else {
                 const V v = *reinterpret_cast<const V *>(&key[e]);
 #pragma unroll
-                for (int i = 0; i < NV; ++i) acc[j + i] = mul_acc<T>(acc[j + i], r[j + i], v[i], P, generic);
+                for (int i = 0; i < NV; ++i) acc[j + i] = mul_acc_cls<T, CLS>(acc[j + i], r[j + i], v[i], P);
             }
         }
     }
@@ -764,15 +793,28 @@ struct ExtWp {
                 const uint32_t jn = j + 1 < nterms ? j + 1 : j;  // last iteration: harmless re-read
                 T nx[E];
                 FB::template gather<IO_RM>(nx, tb + ((size_t)jn << LOGN), ebaseIO, false);
+#pragma unroll
+                for (int e = 0; e < E; ++e) r[e] = Bfly<T, CLS>::load_fix(r[e]);
                 if constexpr (RM0 != IO_RM) {
                     FB::template scatter<IO_RM>(r, lds, ebaseIO, true);
                     F::wsync();
                     FB::template gather<RM0>(r, (const T *)lds, ebase0, true);
                     F::wsync();
                 }
-                F::template pass<0>(r, lds, tid, twf, imgf, P);  // canonical NTT-domain values, layout RMM
+                // NTT-domain values in layout RMM: canonical, or (CLS_FP) range-reduced doubles
+                F::template pass<0, false, true, CLS != CLS_FP>(r, lds, tid, twf, imgf, P);
+                if constexpr (CLS == CLS_FP) {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) r[e] = Bfly<T, CLS>::reduce(r[e], P);
+                }
                 static_for<0, NOUT>([&](auto o) {
                     mul_acc_key(acc[o.value], r, key_ntt + (((size_t)j * NOUT + o.value) << LOGN), ebaseM, P);
+                    if constexpr (CLS == CLS_FP) {  // every product adds at most 0.7 p to the lazy accumulator
+                        if ((j & 7u) == 7u) {
+#pragma unroll
+                            for (int e = 0; e < E; ++e) acc[o.value][e] = Bfly<T, CLS>::reduce(acc[o.value][e], P);
+                        }
+                    }
                 });
                 F::wsync();  // the forward transform's last exchange has been read before LDS is reused
 #pragma unroll
@@ -780,6 +822,10 @@ struct ExtWp {
             }
             static_for<0, NOUT>([&](auto o) {
                 T(&a)[E] = acc[o.value];
+                if constexpr (CLS == CLS_FP) {  // the inverse expects |inputs| <= p
+#pragma unroll
+                    for (int e = 0; e < E; ++e) a[e] = Bfly<T, CLS>::reduce(a[e], P);
+                }
                 I::template pass<0>(a, lds, tid, twi, imgi, P);  // canonical coefficients, layout RML
                 if constexpr (RML != IO_RM) {
                     F::wsync();

@@ -1,0 +1,48 @@
+// One launch of the fused product kernel (MulWp) for a fixed (T, LOGN, CLS) and its workgroup shape.  Shared by the
+// integer-class instantiation units (ntt_mul_inst.inc) and the CLS_FP unit (ntt_inst_u64_fp.hip).
+#pragma once
+#include "ntt_kernel.hpp"
+#include "ntt_launch.hpp"
+
+namespace cntt {
+
+// Workgroup shape of the fused product kernel: as many wavefronts per CU as LDS (160 KiB: one exchange buffer per
+// polynomial in flight + the forward and inverse twiddle images, shared by the workgroup) and registers allow,
+// up to 12 (three per SIMD, 168 VGPRs).  256-thread workgroups when three of them fit; otherwise ONE 768-thread
+// workgroup per CU, which pays for the images once (16 coefficients per thread only: the 32-coefficient u32
+// kernels need more than 168 registers); otherwise 256 x 2 or 512 x 1.
+template <class T, int LOGN> struct MulShape {
+    using K0 = NttKernel<T, LOGN, false, CLS_LAZY, false>;
+    static constexpr size_t IMG = (size_t)K0::IMG_ENTRIES * sizeof(TwPair<T>);
+    static constexpr size_t LDS_MAX = 160 * 1024;
+    static constexpr size_t lds(int block) { return (size_t)block * K0::E * sizeof(T) + 2 * IMG; }
+    static constexpr bool THREE_SMALL = 3 * lds(256) <= LDS_MAX && K0::E == 16;
+    static constexpr bool ONE_BIG = !THREE_SMALL && lds(768) <= LDS_MAX && K0::E == 16 && K0::TPP <= 256 && 768 % K0::TPP == 0;
+    static constexpr bool TWO_SMALL = 2 * lds(256) <= LDS_MAX;
+    static constexpr int BLOCK = THREE_SMALL ? 256 : ONE_BIG ? 768 : TWO_SMALL ? 256 : 512;
+    static constexpr int PER_CU = THREE_SMALL ? 3 : ONE_BIG ? 1 : TWO_SMALL ? 2 : 1;
+    static constexpr int WAVES_PER_SIMD = BLOCK / 64 * PER_CU / 4;  // __launch_bounds__ second argument (HIP: per EU)
+    static_assert(lds(BLOCK) * PER_CU <= LDS_MAX, "fused product kernel does not fit LDS");
+};
+
+static int mul_num_cus() {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    return n;
+}
+
+template <class T, int LOGN, int CLS>
+static hipError_t mul_one(T *lhs, const T *rhs, const TwPair<T> *twf, const TwPair<T> *twi, const ModParams<T> &P,
+                          uint32_t nsub, hipStream_t stream) {
+    using SH = MulShape<T, LOGN>;
+    using K = MulWp<T, LOGN, CLS, SH::BLOCK>;
+    const uint32_t ntiles = (nsub + K::PPB - 1) / K::PPB;
+    uint32_t grid = (uint32_t)mul_num_cus() * SH::PER_CU;
+    if (grid > ntiles) grid = ntiles;
+    hipLaunchKernelGGL((mul_kernel_wp<T, LOGN, CLS, SH::BLOCK, SH::WAVES_PER_SIMD>), dim3(grid), dim3(SH::BLOCK), 0, stream,
+                       lhs, rhs, twf, twi, P, nsub);
+    return hipGetLastError();
+}
+
+}  // namespace cntt

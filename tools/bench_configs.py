@@ -163,6 +163,13 @@ if __name__ == "__main__":
     if "c4" in which:
         prime_case(prime64, 64, 16384, P62, 4096, "prime64 (C4 shard slice)")
         prime_case(prime64, 64, 4096, P62, 16384, "prime64")
+    if "fp" in which:   # CLS_FP (p < 2^50): the 50-bit bench prime of benches/ntt.rs:112
+        P50 = 1125899904679937
+        prime_case(prime64, 64, 256, P50, 262144, "prime64 50-bit")
+        prime_case(prime64, 64, 1024, P50, 65536, "prime64 50-bit")
+        prime_case(prime64, 64, 2048, P50, 32768, "prime64 50-bit")
+        prime_case(prime64, 64, 4096, P50, 16384, "prime64 50-bit")
+        prime_case(prime64, 64, 16384, P50, 4096, "prime64 50-bit")
     if "p64n2048" in which:
         prime_case(prime64, 64, 2048, P62, 32768, "prime64")
     if "c3" in which:
