@@ -159,8 +159,8 @@ __global__ __launch_bounds__(BLK, 2) void native_polymul_kernel(typename NativeS
                                                              const CrtArgs C, uint32_t batch) {
     using SH = NativeShape<KIND>;
     using W = typename SH::W;
-    using Wf = NttWp<uint32_t, LOGN, false, CLS_LAZY, BLK, false, 1>;
-    using Wi = NttWp<uint32_t, LOGN, true, CLS_LAZY, BLK, false, 1>;
+    using Wf = NttWp<uint32_t, LOGN, false, CLS_LAZY, BLK, 1>;
+    using Wi = NttWp<uint32_t, LOGN, true, CLS_LAZY, BLK, 1>;
     constexpr int E = Wf::E, TPP = Wf::TPP, NPASS = Wf::NPASS, PPB = BLK / TPP, KP = SH::KP;
     constexpr uint32_t FULL = Wf::FULL, RM0 = Wf::S::RMASK[0];
     static_assert(RM0 == Wi::S::RMASK[NPASS - 1] && Wf::S::RMASK[NPASS - 1] == Wi::S::RMASK[0],

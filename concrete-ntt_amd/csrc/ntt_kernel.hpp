@@ -73,28 +73,8 @@ template <> struct VecOf<uint32_t, 1> { using type = uint32_t; };
 template <> struct VecOf<uint32_t, 2> { using type = __attribute__((ext_vector_type(2))) uint32_t; };
 template <> struct VecOf<uint32_t, 4> { using type = __attribute__((ext_vector_type(4))) uint32_t; };
 
-// lab-only clock stamps (tools/ntt_lab.hip): per-wave shader-clock and 100 MHz real-time deltas
-__device__ unsigned long long *cntt_lab_buf;  // 2 slots per wave, set by the lab before launching
-struct LabStamp {
-    unsigned long long t0, r0;
-    __device__ __forceinline__ void begin() {
-        t0 = __builtin_amdgcn_s_memtime();
-        r0 = __builtin_amdgcn_s_memrealtime();
-    }
-    __device__ __forceinline__ void end() {
-        const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
-        if ((threadIdx.x & 63) == 0) {
-            const size_t w = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-            cntt_lab_buf[2 * w] = t1 - t0;
-            cntt_lab_buf[2 * w + 1] = r1 - r0;
-        }
-    }
-};
-
 // ---- the kernel -----------------------------------------------------------------------------
-// LAB: ablation flags for tools/ntt_lab.hip only (product instantiations use 0):
-//   1 = no per-thread twiddle loads, 2 = no LDS exchange, 4 = no global load/store, 8 = stamp clocks
-template <class T, int LOGN, bool INV, int CLS, bool SUB, int LAB = 0, int FAM = 0>
+template <class T, int LOGN, bool INV, int CLS, bool SUB, int FAM = 0>
 struct NttKernel {
     using elem_t = T;
     static constexpr int BITS = sizeof(T) * 8;
@@ -215,31 +195,19 @@ struct NttKernel {
     using AsyncVec = __attribute__((ext_vector_type(4))) uint32_t;
     template <uint32_t RM> static constexpr bool async_ok() { return vec_elems<RM>() == MAXV; }
 
-    // The loads use the saddr form (SGPR-pair tile base + 32-bit VGPR byte offset + 13-bit immediate): the per-vector
-    // element offsets cdep(j, RM) are compile-time constants and go into the instruction, one VGPR offset per 4 KiB
-    // window of the tile.
+    // The loads use the saddr form (SGPR-pair base + 32-bit VGPR byte offset + 13-bit immediate): the per-vector
+    // element offsets cdep(j, RM) are compile-time constants.
     template <uint32_t RM, int JV = 0>
-    static __device__ __forceinline__ void gather_async_from(AsyncVec (&v)[E / MAXV], const T *tile, uint32_t woff, int window) {
+    static __device__ __forceinline__ void gather_async(AsyncVec (&v)[E / MAXV], const T *tile, uint32_t voff) {
         if constexpr (JV < E / MAXV) {
+            // the 4 KiB window of a vector goes into the scalar base (SALU add), the rest into the immediate: one VGPR
+            // offset serves the whole tile
             constexpr uint32_t BYTE = cdep((uint32_t)(JV * MAXV), RM) * (uint32_t)sizeof(T);
-            constexpr int WIN = (int)(BYTE >> 12);
-            constexpr uint32_t IMM = BYTE & 4095u;
-            if (WIN == window)
-                asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(v[JV]) : "v"(woff), "s"(tile), "n"(IMM) : "memory");
-            gather_async_from<RM, JV + 1>(v, tile, woff, window);
+            constexpr uint32_t WIN = BYTE & ~4095u, IMM = BYTE & 4095u;
+            const char *base = reinterpret_cast<const char *>(tile) + WIN;
+            asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(v[JV]) : "v"(voff), "s"(base), "n"(IMM) : "memory");
+            gather_async<RM, JV + 1>(v, tile, voff);
         }
-    }
-    template <uint32_t RM> static constexpr int async_windows() {
-        int w = 0;
-        for (int jv = 0; jv < E / MAXV; ++jv) {
-            const int win = (int)((cdep((uint32_t)(jv * MAXV), RM) * (uint32_t)sizeof(T)) >> 12);
-            if (win > w) w = win;
-        }
-        return w + 1;
-    }
-    template <uint32_t RM> static __device__ __forceinline__ void gather_async(AsyncVec (&v)[E / MAXV], const T *tile, uint32_t voff) {
-#pragma unroll
-        for (int w = 0; w < async_windows<RM>(); ++w) gather_async_from<RM>(v, tile, voff + (uint32_t)w * 4096u, w);
     }
     // wait until at most YOUNGER vector-memory operations (issued after the async loads) are outstanding
     template <int YOUNGER> static __device__ __forceinline__ void wait_async(AsyncVec (&v)[E / MAXV]) {
@@ -348,7 +316,7 @@ struct NttKernel {
 
     // NORM (inverse only): the stage on the top index bit -- the last one, one twiddle inv_twid[1] for all of its
     // butterflies -- also applies the 1/N normalisation (Bfly::inv_norm).
-    template <int K, int GI, bool IMG = false, bool NORM = false>
+    template <int K, int GI, bool IMG = false, bool NORM = false, int TWC = 0>
     static __device__ __forceinline__ void stage(T (&r)[E], uint32_t ebase, uint32_t qpre, uint32_t depth,
                                                  const TwPair<T> *__restrict__ tw, const ModParams<T> &P,
                                                  uint32_t tid = 0, const TwPair<T> *img = nullptr) {
@@ -369,28 +337,38 @@ struct NttKernel {
             }
             return;
         }
-        TwPair<T> w[NHI];
+        // Twiddles of the stage, TWC at a time: all NHI at once when they come from LDS or scalar loads; kernels that
+        // read thread-dependent twiddles from global memory (TWC > 0) bound the registers those loads hold.
+        constexpr StageGeom g = geom(K, GI);
+        constexpr bool UNI = g.uniform && !SUB;
+        constexpr bool CHUNKED = TWC > 0 && !UNI && !(IMG && !g.uniform) && NHI > TWC;
+        constexpr int CH = CHUNKED ? TWC : NHI;
 #pragma unroll
-        for (int h = 0; h < NHI; ++h) {
-            constexpr StageGeom g = geom(K, GI);
-            if constexpr ((LAB & 1) != 0)
-                w[h] = tw[(1u << (LOGN - 1 - b)) + (uint32_t)h];  // uniform address: scalar load
-            else if constexpr (IMG && !g.uniform)
-                w[h] = img[img_off(K, GI) + h * g.d + (tid >> g.shift)];
-            else
-                w[h] = tw[toff + (cdep((uint32_t)h << (k + 1), RM) >> (b + 1))];
-        }
+        for (int h0 = 0; h0 < NHI; h0 += CH) {
+            TwPair<T> w[CH];
 #pragma unroll
-        for (int j = 0; j < E; ++j) {
-            if ((j >> k) & 1) continue;
-            const int h = j >> (k + 1);
-            // twiddles that do not depend on the thread come from scalar loads and stay in SGPRs (never for the
-            // sub-block kernels: their table prefix depends on the polynomial a thread works on)
-            constexpr bool UNI = geom(K, GI).uniform && !SUB && (LAB & 1) == 0;
-            if constexpr (INV)
-                Bfly<T, CLS>::template inv<UNI>(r[j], r[j | (1 << k)], w[h].w, w[h].ws, P);
-            else
-                Bfly<T, CLS>::template fwd<UNI>(r[j], r[j | (1 << k)], w[h].w, w[h].ws, P);
+            for (int hh = 0; hh < CH; ++hh) {
+                const int h = h0 + hh;
+                if constexpr (IMG && !g.uniform)
+                    w[hh] = img[img_off(K, GI) + h * g.d + (tid >> g.shift)];
+                else  // uniform table base + 32-bit byte offset: the saddr form of global_load, no 64-bit VGPR address
+                    w[hh] = *reinterpret_cast<const TwPair<T> *>(
+                        reinterpret_cast<const char *>(tw) +
+                        (toff + (cdep((uint32_t)h << (k + 1), RM) >> (b + 1))) * (uint32_t)sizeof(TwPair<T>));
+            }
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                if ((j >> k) & 1) continue;
+                const int h = j >> (k + 1);
+                if (h < h0 || h >= h0 + CH) continue;
+                // twiddles that do not depend on the thread come from scalar loads and stay in SGPRs (never for the
+                // sub-block kernels: their table prefix depends on the polynomial a thread works on)
+                if constexpr (INV)
+                    Bfly<T, CLS>::template inv<UNI>(r[j], r[j | (1 << k)], w[h - h0].w, w[h - h0].ws, P);
+                else
+                    Bfly<T, CLS>::template fwd<UNI>(r[j], r[j | (1 << k)], w[h - h0].w, w[h - h0].ws, P);
+            }
+            if constexpr (CHUNKED) __builtin_amdgcn_sched_barrier(0);  // keep the chunks (and their registers) apart
         }
         if constexpr (CLS == CLS_FP) {
             // range reductions of the double-held residues (bounds: Bfly<T, CLS_FP>): forward, every value after every
@@ -409,13 +387,13 @@ struct NttKernel {
         }
     }
 
-    template <int K, int GI = 0, bool IMG = false, bool NORM = false>
+    template <int K, int GI = 0, bool IMG = false, bool NORM = false, int TWC = 0>
     static __device__ __forceinline__ void stages(T (&r)[E], uint32_t ebase, uint32_t qpre, uint32_t depth,
                                                   const TwPair<T> *__restrict__ tw, const ModParams<T> &P,
                                                   uint32_t tid = 0, const TwPair<T> *img = nullptr) {
         if constexpr (GI < cpop(S::GMASK[K])) {
-            stage<K, GI, IMG, NORM>(r, ebase, qpre, depth, tw, P, tid, img);
-            stages<K, GI + 1, IMG, NORM>(r, ebase, qpre, depth, tw, P, tid, img);
+            stage<K, GI, IMG, NORM, TWC>(r, ebase, qpre, depth, tw, P, tid, img);
+            stages<K, GI + 1, IMG, NORM, TWC>(r, ebase, qpre, depth, tw, P, tid, img);
         }
     }
 
@@ -426,32 +404,21 @@ struct NttKernel {
         constexpr uint32_t RM = S::RMASK[K], CM = FULL & ~RM;
         const uint32_t ebase = pdep<CM>(tid);
         if constexpr (K == 0) {
-            if constexpr ((LAB & 4) == 0) {
-                if (active) gather<RM>(r, (const T *)g, ebase, false);
+            if (active) gather<RM>(r, (const T *)g, ebase, false);
 #pragma unroll
-                for (int j = 0; j < E; ++j) r[j] = Bfly<T, CLS>::load_fix(r[j]);
-            }
-        } else if constexpr ((LAB & 2) == 0) {
+            for (int j = 0; j < E; ++j) r[j] = Bfly<T, CLS>::load_fix(r[j]);
+        } else {
             gather<RM>(r, (const T *)lds, ebase, true);
         }
         stages<K>(r, ebase, qpre, depth, tw, P);
         if constexpr (K == NPASS - 1) {
 #pragma unroll
             for (int j = 0; j < E; ++j) r[j] = INV ? Bfly<T, CLS>::finish_inv(r[j], P) : Bfly<T, CLS>::finish_fwd(r[j], P);
-            if constexpr ((LAB & 4) == 0) {
-                if (active) scatter<RM>(r, g, ebase, false);
-            } else {
-                T acc = 0;  // keep the work alive without the stores
-#pragma unroll
-                for (int j = 0; j < E; ++j) acc ^= r[j];
-                if (acc == (T)0x1234567) g[0] = acc;
-            }
+            if (active) scatter<RM>(r, g, ebase, false);
         } else {
-            if constexpr ((LAB & 2) == 0) {
-                if constexpr (K > 0) sync();  // everyone has read the previous exchange before it is overwritten
-                scatter<RM>(r, lds, ebase, true);
-                sync();
-            }
+            if constexpr (K > 0) sync();  // everyone has read the previous exchange before it is overwritten
+            scatter<RM>(r, lds, ebase, true);
+            sync();
             run_pass<K + 1>(r, g, lds, tid, active, qpre, depth, tw, P);
         }
     }
@@ -468,11 +435,8 @@ struct NttKernel {
         if constexpr (SUB) qpre = (sub & ((1u << depth) - 1u)) << LOGN;
         T r[E];
 #pragma unroll
-        for (int j = 0; j < E; ++j) r[j] = (LAB & 4) ? (T)(threadIdx.x * 77u + j) : (T)0;
-        LabStamp st;
-        if constexpr ((LAB & 8) != 0) st.begin();
+        for (int j = 0; j < E; ++j) r[j] = 0;
         run_pass<0>(r, g, lds, tid, active, qpre, depth, tw, P);
-        if constexpr ((LAB & 8) != 0) st.end();
     }
 };
 
@@ -483,9 +447,9 @@ struct NttKernel {
 // vector-memory wait sits inside the compute phase (twiddles come from LDS / scalar loads), so HBM
 // streaming overlaps the VALU-bound passes instead of alternating with them.
 // -------------------------------------------------------------------------------------------------
-template <class T, int LOGN, bool INV, int CLS, int WPB, bool STAMP = false, int FAM = 0>
-struct NttWp : NttKernel<T, LOGN, INV, CLS, false, 0, FAM> {
-    using B = NttKernel<T, LOGN, INV, CLS, false, 0, FAM>;
+template <class T, int LOGN, bool INV, int CLS, int WPB, int FAM = 0>
+struct NttWp : NttKernel<T, LOGN, INV, CLS, false, FAM> {
+    using B = NttKernel<T, LOGN, INV, CLS, false, FAM>;
     using S = typename B::S;
     static constexpr int E = B::E, TPP = B::TPP, NPASS = B::NPASS;
     static constexpr int BLOCK = WPB, PPB = WPB / TPP;
@@ -509,18 +473,18 @@ struct NttWp : NttKernel<T, LOGN, INV, CLS, false, 0, FAM> {
     // global memory (L2), for kernels that walk several primes and cannot hold an image per prime
     // FIN: bring the outputs into [0, p) (what memory holds); fused kernels whose next step takes the class's lazy
     // register form (CLS_FP products) skip it
-    template <int K, bool NORM = false, bool IMG = true, bool FIN = true>
+    template <int K, bool NORM = false, bool IMG = true, bool FIN = true, int TWC = 0>
     static __device__ __forceinline__ void pass(T (&r)[E], T *lds, uint32_t tid, const TwPair<T> *__restrict__ tw,
                                                 const TwPair<T> *img, const ModParams<T> &P) {
         constexpr uint32_t RM = S::RMASK[K], CM = FULL & ~RM;
         const uint32_t ebase = pdep<CM>(tid);
         if constexpr (K > 0) B::template gather<RM>(r, (const T *)lds, ebase, true);
-        B::template stages<K, 0, IMG, NORM>(r, ebase, 0u, 0u, tw, P, tid, img);
+        B::template stages<K, 0, IMG, NORM, TWC>(r, ebase, 0u, 0u, tw, P, tid, img);
         if constexpr (K < NPASS - 1) {
             if constexpr (K > 0) wsync();
             B::template scatter<RM>(r, lds, ebase, true);
             wsync();
-            pass<K + 1, NORM, IMG, FIN>(r, lds, tid, tw, img, P);
+            pass<K + 1, NORM, IMG, FIN, TWC>(r, lds, tid, tw, img, P);
         } else if constexpr (FIN) {
 #pragma unroll
             for (int j = 0; j < E; ++j) r[j] = INV ? Bfly<T, CLS>::finish_inv(r[j], P) : Bfly<T, CLS>::finish_fwd(r[j], P);
@@ -533,12 +497,15 @@ struct NttWp : NttKernel<T, LOGN, INV, CLS, false, 0, FAM> {
     static constexpr int VB = (B::MAXV == 4) ? 2 : 1;
     static constexpr uint32_t IO_RM = ((1u << VB) - 1u) | (((1u << (B::LOGE - VB)) - 1u) << (LOGN - (B::LOGE - VB)));
 
+    // USE_IMG = false: no LDS twiddle image (sizes whose image does not fit next to the exchange buffer): the
+    // thread-dependent twiddles are read from the table in global memory (L2) inside the passes.
+    template <bool USE_IMG = true>
     static __device__ __forceinline__ void run(T *__restrict__ data, const TwPair<T> *__restrict__ tw,
                                                const ModParams<T> &P, uint32_t nsub, T *lds_all, TwPair<T> *img) {
-        LabStamp st;
-        if constexpr (STAMP) st.begin();
-        B::fill_image(img, tw);
-        __syncthreads();
+        if constexpr (USE_IMG) {
+            B::fill_image(img, tw);
+            __syncthreads();
+        }
         const uint32_t tid = threadIdx.x & (TPP - 1);
         const uint32_t pl = threadIdx.x / TPP;
         T *lds = lds_all + ((size_t)pl << LOGN);
@@ -563,30 +530,38 @@ struct NttWp : NttKernel<T, LOGN, INV, CLS, false, 0, FAM> {
             const uint32_t tnext = tile + gridDim.x;
             const bool more = tnext < ntiles;  // workgroup-uniform
             T *tbase = data + (((size_t)tile * PPB) << LOGN);
+            // Without the image every address of the tile body (layout offsets, twiddle table offsets) is recomputed
+            // per tile from an opaque copy of the thread index: left to itself hipcc hoists all of them out of the
+            // tile loop and then spills the lot.
+            uint32_t tidv = tid;
+            if constexpr (!USE_IMG) asm volatile("" : "+v"(tidv));
+            const uint32_t eb0 = USE_IMG ? ebase0 : pdep<CM0>(tidv), ebL = USE_IMG ? ebaseL : pdep<CML>(tidv);
+            const uint32_t ebIO = USE_IMG ? ebaseIO : pdep<CMIO>(tidv);
+            const uint32_t voff = USE_IMG ? voffIO : ((pl << LOGN) + ebIO) * (uint32_t)sizeof(T);
             typename B::AsyncVec vn[E / B::MAXV];
             if (more) {
                 // ragged tail: lanes of polynomials past the end re-read the last polynomial (harmless, in range)
                 const uint32_t last = nsub - 1u - tnext * PPB;
                 const uint32_t pln = pl < last ? pl : last;
                 B::template gather_async<IO_RM>(vn, (const T *)(data + (((size_t)tnext * PPB) << LOGN)),
-                                                ((pln << LOGN) + ebaseIO) * (uint32_t)sizeof(T));
+                                                ((pln << LOGN) + ebIO) * (uint32_t)sizeof(T));
             }
 #pragma unroll
             for (int j = 0; j < E; ++j) r[j] = Bfly<T, CLS>::load_fix(r[j]);  // memory word -> register form
             if constexpr (RM0 != IO_RM) {  // input transpose
-                B::template scatter<IO_RM>(r, lds, ebaseIO, true);
+                B::template scatter<IO_RM>(r, lds, ebIO, true);
                 wsync();
-                B::template gather<RM0>(r, (const T *)lds, ebase0, true);
+                B::template gather<RM0>(r, (const T *)lds, eb0, true);
                 wsync();
             }
-            pass<0>(r, lds, tid, tw, img, P);
+            pass<0, false, USE_IMG, true, USE_IMG ? 0 : 2>(r, lds, tidv, tw, img, P);
             if constexpr (RML != IO_RM) {  // output transpose
                 wsync();
-                B::template scatter<RML>(r, lds, ebaseL, true);
+                B::template scatter<RML>(r, lds, ebL, true);
                 wsync();
-                B::template gather<IO_RM>(r, (const T *)lds, ebaseIO, true);
+                B::template gather<IO_RM>(r, (const T *)lds, ebIO, true);
             }
-            if (sub < nsub) B::template scatter_tile<IO_RM>(r, tbase, voffIO);
+            if (sub < nsub) B::template scatter_tile<IO_RM>(r, tbase, voff);
             wsync();  // the exchange buffer is reused by the next tile
             if (more) {
                 // lanes of inactive polynomials skipped their stores: the counter then allows fewer
@@ -595,17 +570,28 @@ struct NttWp : NttKernel<T, LOGN, INV, CLS, false, 0, FAM> {
                 B::unpack_async(r, vn);
             }
         }
-        if constexpr (STAMP) st.end();
     }
 };
 
-template <class T, int LOGN, bool INV, int CLS, int WPB, int WPW, bool STAMP = false>
+template <class T, int LOGN, bool INV, int CLS, int WPB, int WPW>
 __global__ __launch_bounds__(WPB, WPW) void ntt_kernel_wp(T *__restrict__ data, const TwPair<T> *__restrict__ tw,
                                                       const ModParams<T> P, uint32_t nsub) {
-    using K = NttWp<T, LOGN, INV, CLS, WPB, STAMP>;
+    using K = NttWp<T, LOGN, INV, CLS, WPB>;
     __shared__ __attribute__((aligned(16))) T lds[(size_t)K::PPB << LOGN];
     __shared__ __attribute__((aligned(16))) TwPair<T> img[K::B::IMG_ENTRIES];
     K::run(data, tw, P, nsub, lds, img);
+}
+
+// The same persistent, software-pipelined walk for the sizes whose twiddle image does not fit LDS (u64 N >= 4096,
+// u32 N >= 8192): one polynomial per workgroup of N / E threads (up to 1024), exchange buffer only, twiddles from L2.
+// What it buys over ntt_kernel is the overlap of a polynomial's HBM reads and writes with the butterflies of its
+// neighbours: with one 128 KiB polynomial per CU nothing else hides them.
+template <class T, int LOGN, bool INV, int CLS, int WPB, int WPW>
+__global__ __launch_bounds__(WPB, WPW) void ntt_kernel_wpg(T *__restrict__ data, const TwPair<T> *__restrict__ tw,
+                                                       const ModParams<T> P, uint32_t nsub) {
+    using K = NttWp<T, LOGN, INV, CLS, WPB>;
+    __shared__ __attribute__((aligned(16))) T lds[(size_t)K::PPB << LOGN];
+    K::template run<false>(data, tw, P, nsub, lds, nullptr);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -859,10 +845,10 @@ __global__ __launch_bounds__(WPB, WPW) void ext_kernel_wp(T *__restrict__ out, c
     K::run(out, terms, key_ntt, twf, twi, P, nb, nterms, accumulate != 0, lds, imgf, imgi);
 }
 
-template <class T, int LOGN, bool INV, int CLS, bool SUB, int LAB = 0>
-__global__ __launch_bounds__((NttKernel<T, LOGN, INV, CLS, SUB, LAB>::BLOCK)) void ntt_kernel(
+template <class T, int LOGN, bool INV, int CLS, bool SUB>
+__global__ __launch_bounds__((NttKernel<T, LOGN, INV, CLS, SUB>::BLOCK)) void ntt_kernel(
     T *__restrict__ data, const TwPair<T> *__restrict__ tw, const ModParams<T> P, uint32_t nsub, uint32_t depth) {
-    using K = NttKernel<T, LOGN, INV, CLS, SUB, LAB>;
+    using K = NttKernel<T, LOGN, INV, CLS, SUB>;
     __shared__ __attribute__((aligned(16))) T lds[K::LDS_ELEMS];
     K::run(data, tw, P, nsub, depth, lds);
 }

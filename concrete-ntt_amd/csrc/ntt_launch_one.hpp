@@ -27,6 +27,10 @@ template <class K> static constexpr bool wp_eligible() {
     return K::NPASS > 1 && K::TPP <= WP_BLOCK && (size_t)K::IMG_ENTRIES * sizeof(TwPair<typename K::elem_t>) <= 32768;
 }
 
+// larger LDS-resident sizes (image too big): the same persistent walk with twiddles from L2, one polynomial per
+// workgroup of N / E <= 1024 threads, as many workgroups per CU as LDS and 16 wavefronts (128 VGPRs) allow
+template <class K> static constexpr bool wpg_eligible() { return K::NPASS > 1 && K::TPP >= 256 && K::TPP <= 1024 && K::LOGE <= 4; }
+
 template <class T, int LOGN, bool INV, int CLS, bool SUB>
 static hipError_t launch_one(T *data, const TwPair<T> *tw, const ModParams<T> &P, uint32_t nsub, uint32_t depth,
                              hipStream_t stream) {
@@ -43,6 +47,17 @@ static hipError_t launch_one(T *data, const TwPair<T> *tw, const ModParams<T> &P
         if (grid > ntiles) grid = ntiles;
         hipLaunchKernelGGL((ntt_kernel_wp<T, LOGN, INV, CLS, WP_BLOCK, BPC>), dim3(grid), dim3(WP_BLOCK), 0, stream, data,
                            tw, P, nsub);
+    } else if constexpr (wpg_eligible<K>() && !SUB) {
+        constexpr int WPB = K::TPP;
+        using W = NttWp<T, LOGN, INV, CLS, WPB>;
+        constexpr size_t LDS_BYTES = ((size_t)W::PPB << LOGN) * sizeof(T);
+        constexpr int BY_LDS = (int)((160 * 1024) / LDS_BYTES), BY_WAVES = 16 / (WPB / 64);
+        constexpr int BPC = BY_LDS < BY_WAVES ? BY_LDS : BY_WAVES;
+        static_assert(BPC >= 1, "one polynomial must fit the LDS of a CU");
+        const uint32_t ntiles = (nsub + W::PPB - 1) / W::PPB;
+        uint32_t grid = (uint32_t)num_cus() * BPC;
+        if (grid > ntiles) grid = ntiles;
+        hipLaunchKernelGGL((ntt_kernel_wpg<T, LOGN, INV, CLS, WPB, 4>), dim3(grid), dim3(WPB), 0, stream, data, tw, P, nsub);
     } else {
         const uint32_t grid = (nsub + K::PPB - 1) / K::PPB;
         hipLaunchKernelGGL((ntt_kernel<T, LOGN, INV, CLS, SUB>), dim3(grid), dim3(K::BLOCK), 0, stream, data, tw, P,

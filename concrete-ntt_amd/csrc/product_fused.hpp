@@ -20,7 +20,7 @@ template <int LOGN, int CLS, int BLK>
 __global__ __launch_bounds__(BLK, 2) void product_fwd2_kernel(uint32_t *__restrict__ res32, const uint64_t *__restrict__ standard,
                                                               const ProductFusedTables F, const ProductArgs A, uint32_t batch,
                                                               uint32_t bounded) {
-    using Wf = NttWp<uint32_t, LOGN, false, CLS, BLK, false, 1>;
+    using Wf = NttWp<uint32_t, LOGN, false, CLS, BLK, 1>;
     constexpr int E = Wf::E, TPP = Wf::TPP, NPASS = Wf::NPASS, PPB = BLK / TPP;
     constexpr uint32_t FULL = Wf::FULL, RM0 = Wf::S::RMASK[0], RML = Wf::S::RMASK[NPASS - 1];
     __shared__ __attribute__((aligned(16))) uint32_t lds_all[(size_t)PPB << LOGN];
@@ -57,7 +57,7 @@ template <int LOGN, int CLS, int BLK>
 __global__ __launch_bounds__(BLK, 2) void product_inv2_kernel(uint64_t *__restrict__ standard, uint32_t *__restrict__ res32,
                                                               const ProductFusedTables F, const ProductArgs A, uint32_t batch,
                                                               uint32_t accumulate) {
-    using Wi = NttWp<uint32_t, LOGN, true, CLS, BLK, false, 1>;
+    using Wi = NttWp<uint32_t, LOGN, true, CLS, BLK, 1>;
     constexpr int E = Wi::E, TPP = Wi::TPP, NPASS = Wi::NPASS, PPB = BLK / TPP;
     constexpr uint32_t FULL = Wi::FULL, RM0 = Wi::S::RMASK[0], RML = Wi::S::RMASK[NPASS - 1];
     __shared__ __attribute__((aligned(16))) uint32_t lds_all[(size_t)PPB << LOGN];

@@ -7,7 +7,7 @@ namespace cntt {
 template <int LOGN, int CLS>
 static hipError_t pf_one(bool inv, uint64_t *standard, uint32_t *res32, const ProductFusedTables &F, const ProductArgs &A,
                          uint32_t batch, bool flag, hipStream_t st) {
-    using K0 = NttKernel<uint32_t, LOGN, false, CLS_LAZY, false, 0, 1>;
+    using K0 = NttKernel<uint32_t, LOGN, false, CLS_LAZY, false, 1>;
     if constexpr (K0::NPASS > 1 && K0::TPP <= 256) {
         constexpr int BLK = 256, PPB = BLK / K0::TPP;
         const uint32_t grid = (batch + PPB - 1) / PPB;

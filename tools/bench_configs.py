@@ -163,6 +163,11 @@ if __name__ == "__main__":
     if "c4" in which:
         prime_case(prime64, 64, 16384, P62, 4096, "prime64 (C4 shard slice)")
         prime_case(prime64, 64, 4096, P62, 16384, "prime64")
+    if "bign" in which:   # the persistent large-N kernels: u64 4096..16384, u32 8192..16384
+        for n, b in ((4096, 16384), (8192, 8192), (16384, 4096)):
+            prime_case(prime64, 64, n, P62, b, "prime64 62-bit")
+        for n, b in ((8192, 16384), (16384, 8192), (32768, 4096)):
+            prime_case(prime32, 32, n, P30, b, "prime32 30-bit")
     if "fp" in which:   # CLS_FP (p < 2^50): the 50-bit bench prime of benches/ntt.rs:112
         P50 = 1125899904679937
         prime_case(prime64, 64, 256, P50, 262144, "prime64 50-bit")

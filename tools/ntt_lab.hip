@@ -1,9 +1,11 @@
 // Ablation lab for the headline kernel (prime64 N=1024, lazy class): where does the time go?
-// Variants share the product's kernel source (ntt_kernel.hpp):
-//   baseline kernel with LAB flags: 1 no per-thread twiddle loads, 2 no LDS exchange, 4 no global
-//   load/store; persistent software-pipelined kernel (ntt_kernel_wp).
-// Every row reports HIP-event time, the in-kernel shader clock (s_memtime / s_memrealtime) and the
-// algorithmic-bytes rate; persistent variants are checked bit for bit against the baseline.
+// Everything lab-specific lives HERE; the product headers carry no instrumentation.  The lab composes the product's
+// own building blocks (NttKernel::stages / gather / scatter, NttWp::run):
+//   * "ALU only": the ten butterfly stages of the product schedule on register-resident data, no global traffic, no
+//     LDS exchange, first-stage (uniform) twiddles only -- the VALU ceiling of the transform;
+//   * the product's persistent kernel wrapped with shader-clock / real-time stamps (s_memtime / s_memrealtime);
+//   * the persistent kernel checked bit for bit against the one-polynomial-per-workgroup kernel.
+// Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 tools/ntt_lab.hip -o ntt_lab
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -22,7 +24,24 @@ static const int REPS = 200;
 #define LAB_WPW 3  // waves per SIMD the persistent kernel is compiled for (= workgroups of 256 threads per CU)
 #endif
 
-static unsigned long long *g_stamp;  // device buffer, 2 slots per wave
+// ---- clock stamps: 2 slots per wave -----------------------------------------------------------------------
+__device__ unsigned long long *lab_buf;
+struct LabStamp {
+    unsigned long long t0, r0;
+    __device__ __forceinline__ void begin() {
+        t0 = __builtin_amdgcn_s_memtime();
+        r0 = __builtin_amdgcn_s_memrealtime();
+    }
+    __device__ __forceinline__ void end() {
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        if ((threadIdx.x & 63) == 0) {
+            const size_t w = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+            lab_buf[2 * w] = t1 - t0;
+            lab_buf[2 * w + 1] = r1 - r0;
+        }
+    }
+};
+static unsigned long long *g_stamp;
 static const size_t STAMP_WAVES = 65536 + 1024;
 static void clk_reset() { (void)hipMemset(g_stamp, 0, STAMP_WAVES * 16); }
 static double clk_read_mhz() {
@@ -34,6 +53,41 @@ static double clk_read_mhz() {
         r += (double)hst[2 * w + 1];
     }
     return r > 0 ? 100.0 * t / r : 0;
+}
+
+// ---- lab kernels ---------------------------------------------------------------------------------------------
+// every pass's stages on registers (addresses as thread 0 of the polynomial: uniform twiddles, scalar loads)
+template <class K, int PASS = 0> __device__ __forceinline__ void all_stages(uint64_t (&r)[K::E], const TwPair<uint64_t> *tw,
+                                                                            const ModParams<uint64_t> &P) {
+    if constexpr (PASS < K::NPASS) {
+        K::template stages<PASS>(r, 0u, 0u, 0u, tw, P);
+        all_stages<K, PASS + 1>(r, tw, P);
+    }
+}
+template <bool INV> __global__ __launch_bounds__(256) void lab_alu_only(uint64_t *sink, const TwPair<uint64_t> *tw,
+                                                                       const ModParams<uint64_t> P) {
+    using K = NttKernel<uint64_t, 10, INV, CLS_LAZY, false>;
+    LabStamp st;
+    st.begin();
+    uint64_t r[K::E];
+#pragma unroll
+    for (int j = 0; j < K::E; ++j) r[j] = (uint64_t)(threadIdx.x * 77u + j);
+    all_stages<K>(r, tw, P);
+    uint64_t acc = 0;  // keep the work alive without stores
+#pragma unroll
+    for (int j = 0; j < K::E; ++j) acc ^= r[j];
+    if (acc == 0x1234567ull) sink[0] = acc;
+    st.end();
+}
+template <bool INV, int WPB, int WPW> __global__ __launch_bounds__(WPB, WPW) void lab_wp_stamped(
+    uint64_t *data, const TwPair<uint64_t> *tw, const ModParams<uint64_t> P, uint32_t nsub) {
+    using K = NttWp<uint64_t, 10, INV, CLS_LAZY, WPB>;
+    __shared__ __attribute__((aligned(16))) uint64_t lds[(size_t)K::PPB << 10];
+    __shared__ __attribute__((aligned(16))) TwPair<uint64_t> img[K::B::IMG_ENTRIES];
+    LabStamp st;
+    st.begin();
+    K::run(data, tw, P, nsub, lds, img);
+    st.end();
 }
 
 template <class F> static void timeit(const char *name, F launch) {
@@ -64,43 +118,47 @@ template <class F> static void timeit(const char *name, F launch) {
     (void)hipEventElapsedTime(&ms, e0, e1);
     ms /= REPS;
     const hipError_t err = hipGetLastError();
-    printf("%-30s %8.1f us  %7.1f M NTT/s  %5.1f %% of 8 TB/s  clock %6.0f MHz %s\n", name, ms * 1e3,
+    printf("%-34s %8.1f us  %7.1f M NTT/s  %5.1f %% of 8 TB/s  clock %6.0f MHz %s\n", name, ms * 1e3,
            BATCH / (ms * 1e-3) / 1e6, 100.0 * BATCH * 16384.0 / (ms * 1e-3) / 8e12, clk_read_mhz(),
            err == hipSuccess ? "" : hipGetErrorString(err));
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
 }
 
-template <int LAB0, bool INV> static void base(const char *name) {
-    constexpr int LAB = LAB0 | 8;
-    using K = NttKernel<uint64_t, 10, INV, CLS_LAZY, false, LAB>;
-    const uint32_t grid = (BATCH + K::PPB - 1) / K::PPB;
+template <bool INV> static void product_kernel(const char *name) {  // what cntt_prime64_{fwd,inv}_batch launches at N=1024
+    using W = NttWp<uint64_t, 10, INV, CLS_LAZY, 256>;
+    const uint32_t ntiles = (BATCH + W::PPB - 1) / W::PPB;
+    uint32_t grid = 256u * 3u;
+    if (grid > ntiles) grid = ntiles;
     timeit(name, [&] {
-        hipLaunchKernelGGL((ntt_kernel<uint64_t, 10, INV, CLS_LAZY, false, LAB>), dim3(grid), dim3(K::BLOCK), 0, 0, g_data, g_tw, g_P, BATCH, 0u);
+        hipLaunchKernelGGL((ntt_kernel_wp<uint64_t, 10, INV, CLS_LAZY, 256, 3>), dim3(grid), dim3(256), 0, 0, g_data, g_tw, g_P, BATCH);
     });
 }
-// STAMP (in-kernel clock stamps) only where the kernel still compiles without spills: the persistent kernel's
-// inline-asm prefetch must never meet a spilled register (see ntt_kernel.hpp gather_async).
-template <int WPB, int WPW, bool INV, bool STAMP = !INV> static void wp(const char *name, int blocks_per_cu) {
-    using K = NttWp<uint64_t, 10, INV, CLS_LAZY, WPB, STAMP>;
+template <bool INV> static void alu_only(const char *name) {
+    using K = NttKernel<uint64_t, 10, INV, CLS_LAZY, false>;
+    const uint32_t grid = BATCH / (256 / K::TPP);  // as many threads as the real transform of the batch
+    timeit(name, [&] { hipLaunchKernelGGL((lab_alu_only<INV>), dim3(grid), dim3(256), 0, 0, g_data, g_tw, g_P); });
+}
+template <int WPB, int WPW, bool INV> static void wp_stamped(const char *name, int blocks_per_cu) {
+    using K = NttWp<uint64_t, 10, INV, CLS_LAZY, WPB>;
     const uint32_t ntiles = (BATCH + K::PPB - 1) / K::PPB;
     uint32_t grid = 256u * (uint32_t)blocks_per_cu;
     if (grid > ntiles) grid = ntiles;
     timeit(name, [&] {
-        hipLaunchKernelGGL((ntt_kernel_wp<uint64_t, 10, INV, CLS_LAZY, WPB, WPW, STAMP>), dim3(grid), dim3(WPB), 0, 0, g_data, g_tw, g_P, BATCH);
+        hipLaunchKernelGGL((lab_wp_stamped<INV, WPB, WPW>), dim3(grid), dim3(WPB), 0, 0, g_data, g_tw, g_P, BATCH);
     });
 }
 
-template <int WPB, int WPW, bool INV> static bool check_wp(const std::vector<uint64_t> &src, uint32_t batch, uint32_t grid) {
+template <bool INV> static bool check_wp(const std::vector<uint64_t> &src, uint32_t batch, uint32_t grid) {
     uint64_t *a, *b;
     const size_t bytes = (size_t)batch * 1024 * 8;
     (void)hipMalloc(&a, bytes);
     (void)hipMalloc(&b, bytes);
     (void)hipMemcpy(a, src.data(), bytes, hipMemcpyHostToDevice);
     (void)hipMemcpy(b, src.data(), bytes, hipMemcpyHostToDevice);
-    using K0 = NttKernel<uint64_t, 10, INV, CLS_LAZY, false, 0>;
-    hipLaunchKernelGGL((ntt_kernel<uint64_t, 10, INV, CLS_LAZY, false, 0>), dim3((batch + K0::PPB - 1) / K0::PPB), dim3(K0::BLOCK), 0, 0, a, g_tw, g_P, batch, 0u);
-    hipLaunchKernelGGL((ntt_kernel_wp<uint64_t, 10, INV, CLS_LAZY, WPB, WPW, false>), dim3(grid), dim3(WPB), 0, 0, b, g_tw, g_P, batch);
+    using K0 = NttKernel<uint64_t, 10, INV, CLS_LAZY, false>;
+    hipLaunchKernelGGL((ntt_kernel<uint64_t, 10, INV, CLS_LAZY, false>), dim3((batch + K0::PPB - 1) / K0::PPB), dim3(K0::BLOCK), 0, 0, a, g_tw, g_P, batch, 0u);
+    hipLaunchKernelGGL((ntt_kernel_wp<uint64_t, 10, INV, CLS_LAZY, 256, 3>), dim3(grid), dim3(256), 0, 0, b, g_tw, g_P, batch);
     std::vector<uint64_t> ha((size_t)batch * 1024), hb((size_t)batch * 1024);
     (void)hipMemcpy(ha.data(), a, bytes, hipMemcpyDeviceToHost);
     (void)hipMemcpy(hb.data(), b, bytes, hipMemcpyDeviceToHost);
@@ -117,7 +175,7 @@ int main() {
     (void)hipMalloc(&g_data, (size_t)BATCH * n * 8);
     (void)hipMalloc(&g_tw, n * sizeof(TwPair<uint64_t>));
     (void)hipMalloc(&g_stamp, STAMP_WAVES * 16);
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(cntt_lab_buf), &g_stamp, sizeof g_stamp);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(lab_buf), &g_stamp, sizeof g_stamp);
     std::vector<uint64_t> h((size_t)BATCH * n);
     uint64_t s = 88172645463325252ull;
     for (auto &v : h) {
@@ -135,20 +193,17 @@ int main() {
     g_P = ModParams<uint64_t>{};
     g_P.p = p; g_P.neg_p = 0 - p; g_P.two_p = 2 * p; g_P.neg_two_p = 0 - 2 * p;
 
-    base<0, false>("fwd baseline");
-    base<1, false>("fwd no-twiddle-loads");
-    base<2, false>("fwd no-LDS-exchange");
-    base<4, false>("fwd no-global");
-    base<7, false>("fwd ALU only (1+2+4)");
-    base<0, true>("inv baseline");
-    base<7, true>("inv ALU only (1+2+4)");
+    product_kernel<false>("fwd product kernel (wp 256x3)");
+    product_kernel<true>("inv product kernel (wp 256x3)");
+    alu_only<false>("fwd ALU only (stages on registers)");
+    alu_only<true>("inv ALU only (stages on registers)");
     {
         std::vector<uint64_t> src(h.begin(), h.begin() + (size_t)1333 * 1024);
-        printf("check wp<256,LAB_WPW> fwd %d inv %d\n", (int)check_wp<256, LAB_WPW, false>(src, 1333, 7),
-               (int)check_wp<256, LAB_WPW, true>(src, 1333, 64));
+        printf("check wp vs one-polynomial-per-workgroup kernel: fwd %d inv %d\n", (int)check_wp<false>(src, 1333, 7),
+               (int)check_wp<true>(src, 1333, 64));
     }
-    wp<256, LAB_WPW, false, false>("wp 256thr xLAB_WPW/CU fwd", LAB_WPW);
-    wp<256, LAB_WPW, false, false>("wp 256thr x2/CU fwd", 2);
-    wp<256, LAB_WPW, true, false>("wp 256thr xLAB_WPW/CU inv", LAB_WPW);
+    wp_stamped<256, LAB_WPW, false>("fwd wp stamped, 3 WG/CU", 3);
+    wp_stamped<256, LAB_WPW, false>("fwd wp stamped, 2 WG/CU", 2);
+    wp_stamped<256, LAB_WPW, true>("inv wp stamped, 3 WG/CU", 3);
     return 0;
 }
