@@ -187,13 +187,14 @@ template <class T, class PlanT> static int plan_new(size_t n, T p, PlanT **out) 
         mp.last_w = (T)w_last;
         mp.last_w_shoup = shoup_of<T>((T)w_last, p);
     }
-    // CLS_FP: 64-bit words, p < 2^50 (src/prime64/less_than_50bit.rs's class).  CNTT_DISABLE_FP=1 keeps such plans on the
-    // integer butterflies (A/B measurements, and tests that compare the two paths).
+    // CLS_FP / CLS_FP51: 64-bit words, p < 2^50 / 2^51 (the classes of src/prime64/less_than_50bit.rs and
+    // less_than_51bit.rs).  CNTT_DISABLE_FP=1 keeps such plans on the integer butterflies (A/B measurements, and tests
+    // that compare the two paths).
     mp.fp = 0;
     if constexpr (B == 64) {
         const char *off = std::getenv("CNTT_DISABLE_FP");
-        if (p64 < ((uint64_t)1 << 50) && !(off && off[0] == '1')) {
-            mp.fp = 1;
+        if (p64 < ((uint64_t)1 << 51) && !(off && off[0] == '1')) {
+            mp.fp = p64 < ((uint64_t)1 << 50) ? (uint32_t)CLS_FP : (uint32_t)CLS_FP51;
             const double pd = (double)p64;
             mp.fp_p = host::double_bits(pd);
             mp.fp_pinv = host::double_bits(1.0 / pd);
@@ -211,7 +212,7 @@ template <class T, class PlanT> static int plan_new(size_t n, T p, PlanT **out) 
 
 // transform class of the LDS-resident kernels for this plan (the global-stage path of larger sizes is integer-only)
 template <class T> static int transform_class(const PrimePlan<T> *pl) {
-    return (pl->mp.fp && pl->logn <= MaxLdsLogN<T>::value) ? (int)CLS_FP : (int)pl->mp.cls;
+    return (pl->mp.fp && pl->logn <= MaxLdsLogN<T>::value) ? (int)pl->mp.fp : (int)pl->mp.cls;
 }
 
 // per-device table replica, created on first use under the cache mutex
@@ -306,9 +307,9 @@ template <class T> static int ntt_device(const PrimePlan<T> *pl, T *d, size_t ba
     hipError_t e;
     if (!inv) {
         for (int s = 0; s < depth; ++s) global_stage<T, false>(d, t.fwd, pl->mp, (uint32_t)pl->logn, (uint32_t)s, nbfly, false, st);
-        e = launch_ntt<T, false>(sub_logn, tcls, d, tcls == CLS_FP ? t.fwd_fp : t.fwd, pl->mp, nsub, (uint32_t)depth, st);
+        e = launch_ntt<T, false>(sub_logn, tcls, d, is_fp_class(tcls) ? t.fwd_fp : t.fwd, pl->mp, nsub, (uint32_t)depth, st);
     } else {
-        e = launch_ntt<T, true>(sub_logn, tcls, d, tcls == CLS_FP ? t.inv_fp : t.inv, pl->mp, nsub, (uint32_t)depth, st);
+        e = launch_ntt<T, true>(sub_logn, tcls, d, is_fp_class(tcls) ? t.inv_fp : t.inv, pl->mp, nsub, (uint32_t)depth, st);
         for (int s = depth - 1; s >= 0 && e == hipSuccess; --s)
             global_stage<T, true>(d, t.inv, pl->mp, (uint32_t)pl->logn, (uint32_t)s, nbfly, s == 0, st);
     }
@@ -348,8 +349,8 @@ template <class T> static int mul_ntt_device(const PrimePlan<T> *pl, T *lhs, con
     DeviceTables<T> t;
     if (int rc = device_tables(pl, &t)) return rc;
     const int tcls = transform_class(pl);
-    const hipError_t e = launch_mul_ntt<T>(pl->logn, tcls, lhs, rhs, tcls == CLS_FP ? t.fwd_fp : t.fwd,
-                                           tcls == CLS_FP ? t.inv_fp : t.inv, pl->mp, (uint32_t)batch, st);
+    const hipError_t e = launch_mul_ntt<T>(pl->logn, tcls, lhs, rhs, is_fp_class(tcls) ? t.fwd_fp : t.fwd,
+                                           is_fp_class(tcls) ? t.inv_fp : t.inv, pl->mp, (uint32_t)batch, st);
     if (e == hipSuccess) return CNTT_OK;
     if (e != hipErrorNotSupported) return fail(CNTT_EDEVICE, "fused product launch failed: %s", hipGetErrorString(e));
     (void)hipGetLastError();
@@ -374,8 +375,8 @@ static int external_product_device(const PrimePlan<T> *pl, T *out, const T *term
     DeviceTables<T> t;
     if (int rc = device_tables(pl, &t)) return rc;
     const int tcls = transform_class(pl);
-    const hipError_t e = launch_ext_ntt<T>(pl->logn, tcls, out, terms, key, tcls == CLS_FP ? t.fwd_fp : t.fwd,
-                                           tcls == CLS_FP ? t.inv_fp : t.inv, pl->mp, (uint32_t)batch, (uint32_t)nterms,
+    const hipError_t e = launch_ext_ntt<T>(pl->logn, tcls, out, terms, key, is_fp_class(tcls) ? t.fwd_fp : t.fwd,
+                                           is_fp_class(tcls) ? t.inv_fp : t.inv, pl->mp, (uint32_t)batch, (uint32_t)nterms,
                                            (uint32_t)nout, accumulate, st);
     if (e == hipSuccess) return CNTT_OK;
     if (e != hipErrorNotSupported) return fail(CNTT_EDEVICE, "fused mul_accumulate chain launch failed: %s", hipGetErrorString(e));

@@ -14,14 +14,16 @@
 //               native plan): the LDS-resident transforms keep each residue as an IEEE double holding an exact
 //               integer representative |v| < 2^53 and multiply with v_fma_f64 -- on gfx950 a double FMA
 //               issues at the rate of ONE 32-bit integer multiply, and an exact 50 x 53-bit modular product
-//               is six of them instead of ten integer multiplies and their carry chains (see Bfly<T, CLS_FP>).
+//               is six of them instead of ten integer multiplies and their carry chains (see BflyFp).
+//   CLS_FP51    the same for 2^50 <= p < 2^51 (src/prime64/less_than_51bit.rs): 2^53 is only 4p there, so the range
+//               reductions come more often.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace cntt {
 
-enum : int { CLS_LAZY = 0, CLS_STRICT = 1, CLS_GENERIC = 2, CLS_FP = 3 };
+enum : int { CLS_LAZY = 0, CLS_STRICT = 1, CLS_GENERIC = 2, CLS_FP = 3, CLS_FP51 = 4 };
 
 // One table entry: the twiddle and its Shoup companion floor(w * 2^B / p) (CLS_GENERIC: w holds
 // w * 2^B mod p and ws is unused).  Interleaved so that one 16-byte (u64) / 8-byte (u32) load
@@ -47,7 +49,7 @@ template <class T> struct ModParams {
     T fp_p, fp_pinv, fp_n_inv, fp_n_inv_q, fp_last_w, fp_last_w_q;
     uint32_t big_q;        // floor(log2 p) + 1
     uint32_t cls;          // integer arithmetic class (pointwise kernels, global stages, every non-FP transform)
-    uint32_t fp;           // 1: the LDS-resident transforms of this plan run in CLS_FP
+    uint32_t fp;           // CLS_FP / CLS_FP51: class of the LDS-resident transforms of this plan (0: cls)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -246,6 +248,7 @@ template <class T, int CLS> struct Bfly {
             x = mont_mul(x, P.n_inv, P.p, P.pinv_neg);  // n_inv field = N^-1 R^2: x / R * (N^-1 R^2) / R ... see mul_for_inv
         }
     }
+    static constexpr bool IS_FP = false;
     // a word as loaded from memory -> the class's register form (identity for the integer classes)
     static __device__ __forceinline__ T load_fix(T v) { return v; }
     static __device__ __forceinline__ T reduce(T v, const ModParams<T> &) { return v; }
@@ -262,18 +265,22 @@ template <class T, int CLS> struct Bfly {
 };
 
 // ---------------------------------------------------------------------------------------------
-// CLS_FP: residues as exact integers in doubles (64-bit words, p < 2^50)
+// CLS_FP / CLS_FP51: residues as exact integers in doubles (64-bit words, p < 2^50 / p < 2^51)
 //
 // A register holds the bit pattern of a double v, an exact integer with v = residue (mod p) and |v| < 2^53.
 // Product by a table constant c (centred, |c| <= p/2) with its companion cq = fl(c / p):
 //     h = fl(y c)   l = fma(y, c, -h) (exact error term)   q = rint(fl(y cq))   r = fma(-q, p, h) (exact)   t = r + l
 // y c - q p = t exactly, and |q - y c / p| <= 1/2 + |y| 2^-53, so |t| <= (1/2 + |y| 2^-53) p; h - q p = t - l is an
-// integer below 2^53 because |l| <= ulp(h)/2 <= |y| p 2^-54.  Every sum x +- t is exact while it stays below 2^53 >
-// 8p, which the kernels guarantee by a range reduction v - p rint(v / p) (three instructions) every few stages:
-//     forward  (x, y) <- (x + t, x - t): the bound grows by <= (1/2 + B 2^-53) p per stage: from p (canonical input)
-//              1.63p, 2.33p, 3.12p, 4.01p, 5.01p; from p/2 (after a reduction) 1.06p ... 4.11p -> reduce every fifth stage;
-//     inverse  (x, y) <- (x + y, (x - y) w): sums double, products come back below p (|x - y| <= 4p): inputs <= p give
-//              2p, then 4p -> the sums are reduced after every second stage, so |x - y| <= 4p and |x + y| <= 4p always.
+// integer below 2^53 because |l| <= ulp(h)/2 <= |y| p 2^-54.  Every sum x +- t is exact while it stays below 2^53,
+// which the kernels guarantee by a range reduction v - p rint(v / p) (three instructions) every few stages.
+// With H = 2^53 / p (> 8 for CLS_FP, > 4 for CLS_FP51) and bounds in units of p, B' = B + 1/2 + B/H per stage:
+//   forward  (x, y) <- (x + t, x - t)
+//     H = 8: from 1 (canonical input) 1.63, 2.33, 3.12, 4.01, 5.01; from 1/2 (after a reduction) 1.06 ... 4.11
+//            -> every value is reduced after every FIFTH stage;
+//     H = 4: from 1: 1.75, 2.69, 3.86; from 1/2: 1.13, 1.91, 2.88 -> after every THIRD stage;
+//   inverse  (x, y) <- (x + y, (x - y) w): sums double, products come back below p
+//     H = 8: inputs <= 1 give 2, then 4 -> the sums are reduced after every SECOND stage (|x - y| <= 4 always);
+//     H = 4: the sums are reduced after EVERY stage (inputs <= 1, |x + y| <= 2, |x - y| <= 2, products <= 1).
 // Twiddles come from a table of (c, c/p) doubles built by the host (csrc/host.hip); the public values are the same
 // canonical integers as in every other class: the load turns a canonical word into a double (two instructions) and
 // the store reduces, lifts negatives by p and extracts the integer (nine).
@@ -298,7 +305,7 @@ struct Fp {
         const double r = __fma_rn(-q, p, h);
         return __dadd_rn(r, l);
     }
-    // a * b mod p for two data values, |a|, |b| <= p: |result| <= 0.7 p
+    // a * b mod p for two data values, |a| <= p/2, 0 <= b < p < 2^51: |result| <= 0.875 p
     static __device__ __forceinline__ double mul_data(double a, double b, double p, double pinv) {
         const double h = __dmul_rn(a, b);
         const double q = __builtin_rint(__dmul_rn(h, pinv));
@@ -314,8 +321,13 @@ struct Fp {
     }
 };
 
-template <class T> struct Bfly<T, CLS_FP> {
-    static_assert(sizeof(T) == 8, "CLS_FP is a 64-bit class");
+// HEAD = floor(2^53 / 2^bits(p)): 8 for p < 2^50, 4 for p < 2^51
+template <class T, int HEAD> struct BflyFp {
+    static_assert(sizeof(T) == 8, "the double-precision classes are 64-bit classes");
+    static constexpr bool IS_FP = true;
+    static constexpr int FWD_REDUCE_EVERY = HEAD >= 8 ? 5 : 3;   // forward: every value, after this many stages
+    static constexpr int INV_REDUCE_EVERY = HEAD >= 8 ? 2 : 1;   // inverse: the sums, after this many stages
+    static constexpr int ACC_REDUCE_EVERY = HEAD >= 8 ? 8 : 2;   // mul_accumulate chains: products (<= 0.875 p) per reduction
     static __device__ __forceinline__ T load_fix(T v) { return Fp::u(Fp::from_word(v)); }
     static __device__ __forceinline__ T reduce(T v, const ModParams<T> &P) {
         return Fp::u(Fp::reduce(Fp::d(v), Fp::d(P.fp_p), Fp::d(P.fp_pinv)));
@@ -343,6 +355,9 @@ template <class T> struct Bfly<T, CLS_FP> {
     }
     static __device__ __forceinline__ T finish_inv(T v, const ModParams<T> &P) { return finish_fwd(v, P); }
 };
+template <class T> struct Bfly<T, CLS_FP> : BflyFp<T, 8> {};
+template <class T> struct Bfly<T, CLS_FP51> : BflyFp<T, 4> {};
+__host__ __device__ constexpr bool is_fp_class(int cls) { return cls == CLS_FP || cls == CLS_FP51; }
 
 // ---------------------------------------------------------------------------------------------
 // pointwise kernels' arithmetic (src/prime64.rs:534-584,690-699; src/prime32.rs:383-408,...)
@@ -386,8 +401,8 @@ template <class T> __device__ __forceinline__ T mul_normalize(T a, T b, const Mo
 // a*b in the range the inverse butterflies of class CLS accept, WITHOUT the 1/N factor (Bfly::inv_norm applies it):
 // LAZY [0, 2p); STRICT canonical; GENERIC a b / R canonical (inv_norm's constants carry the R^2).
 template <class T, int CLS> __device__ __forceinline__ T mul_for_inv(T a, T b, const ModParams<T> &P) {
-    if constexpr (CLS == CLS_FP) {
-        // a: the forward transform's lazy double (|a| < 8p), b: a canonical word from memory; result |.| <= 0.7 p
+    if constexpr (is_fp_class(CLS)) {
+        // a: the forward transform's lazy double (|a| < 2^53), b: a canonical word from memory; result |.| <= 0.875 p
         const double p = Fp::d(P.fp_p), pinv = Fp::d(P.fp_pinv);
         return Fp::u(Fp::mul_data(Fp::reduce(Fp::d(a), p, pinv), Fp::from_word(b), p, pinv));
     } else if constexpr (CLS == CLS_GENERIC) {
@@ -419,9 +434,9 @@ template <class T> __device__ __forceinline__ T mul_acc(T acc, T a, T b, const M
 }
 
 // acc + a * b in the accumulator form of class CLS (the fused mul_accumulate chains): the integer classes keep
-// canonical accumulators; CLS_FP adds the product (|.| <= 0.7 p, `a` already range-reduced) to a lazy double.
+// canonical accumulators; the double classes add the product (|.| <= 0.875 p, `a` already range-reduced) to a lazy double.
 template <class T, int CLS> __device__ __forceinline__ T mul_acc_cls(T acc, T a, T b, const ModParams<T> &P) {
-    if constexpr (CLS == CLS_FP) {
+    if constexpr (is_fp_class(CLS)) {
         const double p = Fp::d(P.fp_p), pinv = Fp::d(P.fp_pinv);
         return Fp::u(__dadd_rn(Fp::d(acc), Fp::mul_data(Fp::d(a), Fp::from_word(b), p, pinv)));
     } else {

@@ -370,19 +370,20 @@ struct NttKernel {
             }
             if constexpr (CHUNKED) __builtin_amdgcn_sched_barrier(0);  // keep the chunks (and their registers) apart
         }
-        if constexpr (CLS == CLS_FP) {
-            // range reductions of the double-held residues (bounds: Bfly<T, CLS_FP>): forward, every value after every
-            // fifth stage; inverse, the sums after every second stage.  The last stage is followed by finish_*.
-            static_assert(!SUB, "CLS_FP covers whole LDS-resident transforms only");
+        if constexpr (Bfly<T, CLS>::IS_FP) {
+            // range reductions of the double-held residues (bounds and periods: BflyFp in ntt_arith.hpp).  The last
+            // stage is followed by finish_*.
+            static_assert(!SUB, "the double-precision classes cover whole LDS-resident transforms only");
+            using BF = Bfly<T, CLS>;
             constexpr int SNO = stage_no(K, GI);
-            if constexpr (!INV && SNO % 5 == 4 && SNO != LOGN - 1) {
+            if constexpr (!INV && SNO % BF::FWD_REDUCE_EVERY == BF::FWD_REDUCE_EVERY - 1 && SNO != LOGN - 1) {
 #pragma unroll
-                for (int j = 0; j < E; ++j) r[j] = Bfly<T, CLS>::reduce(r[j], P);
+                for (int j = 0; j < E; ++j) r[j] = BF::reduce(r[j], P);
             }
-            if constexpr (INV && SNO % 2 == 1 && SNO != LOGN - 1) {
+            if constexpr (INV && SNO % BF::INV_REDUCE_EVERY == BF::INV_REDUCE_EVERY - 1 && SNO != LOGN - 1) {
 #pragma unroll
                 for (int j = 0; j < E; ++j)
-                    if (((j >> k) & 1) == 0) r[j] = Bfly<T, CLS>::reduce(r[j], P);
+                    if (((j >> k) & 1) == 0) r[j] = BF::reduce(r[j], P);
             }
         }
     }
@@ -658,7 +659,7 @@ struct MulWp {
                 F::wsync();
             }
             // NTT-domain values in layout RMM: canonical, or (CLS_FP) the lazy doubles mul_for_inv takes
-            F::template pass<0, false, true, CLS != CLS_FP>(r, lds, tid, twf, imgf, P);
+            F::template pass<0, false, true, !Bfly<T, CLS>::IS_FP>(r, lds, tid, twf, imgf, P);
             {
                 // clamped polynomial index for the reads of a ragged tail
                 const uint32_t lastc = nsub - 1u - tile * PPB;
@@ -788,15 +789,15 @@ struct ExtWp {
                     F::wsync();
                 }
                 // NTT-domain values in layout RMM: canonical, or (CLS_FP) range-reduced doubles
-                F::template pass<0, false, true, CLS != CLS_FP>(r, lds, tid, twf, imgf, P);
-                if constexpr (CLS == CLS_FP) {
+                F::template pass<0, false, true, !Bfly<T, CLS>::IS_FP>(r, lds, tid, twf, imgf, P);
+                if constexpr (Bfly<T, CLS>::IS_FP) {
 #pragma unroll
                     for (int e = 0; e < E; ++e) r[e] = Bfly<T, CLS>::reduce(r[e], P);
                 }
                 static_for<0, NOUT>([&](auto o) {
                     mul_acc_key(acc[o.value], r, key_ntt + (((size_t)j * NOUT + o.value) << LOGN), ebaseM, P);
-                    if constexpr (CLS == CLS_FP) {  // every product adds at most 0.7 p to the lazy accumulator
-                        if ((j & 7u) == 7u) {
+                    if constexpr (Bfly<T, CLS>::IS_FP) {  // every product adds at most 0.875 p to the lazy accumulator
+                        if ((j + 1u) % (uint32_t)Bfly<T, CLS>::ACC_REDUCE_EVERY == 0u) {
 #pragma unroll
                             for (int e = 0; e < E; ++e) acc[o.value][e] = Bfly<T, CLS>::reduce(acc[o.value][e], P);
                         }
@@ -808,7 +809,7 @@ struct ExtWp {
             }
             static_for<0, NOUT>([&](auto o) {
                 T(&a)[E] = acc[o.value];
-                if constexpr (CLS == CLS_FP) {  // the inverse expects |inputs| <= p
+                if constexpr (Bfly<T, CLS>::IS_FP) {  // the inverse expects |inputs| <= p
 #pragma unroll
                     for (int e = 0; e < E; ++e) a[e] = Bfly<T, CLS>::reduce(a[e], P);
                 }

@@ -23,10 +23,12 @@ template <class T, bool INV>
 hipError_t launch_ntt(int logn, int cls, T *data, const TwPair<T> *tw, const ModParams<T> &P, uint32_t nsub,
                       uint32_t depth, hipStream_t stream);
 
-// CLS_FP (64-bit words, p < 2^50) instances of the two launches above, in a translation unit of their own
-// (ntt_inst_u64_fp.hip).  `tw` / `twf` / `twi` are the plan's (c, c/p) double tables.
+// CLS_FP / CLS_FP51 (64-bit words, p < 2^50 / 2^51) instances of the two launches above, each class in a translation
+// unit of its own (ntt_inst_u64_fp.hip, ntt_inst_u64_fp51.hip).  `tw` / `twf` / `twi` are the plan's (c, c/p) double tables.
+template <int CLS>
 hipError_t launch_ntt_fp(int logn, bool inv, uint64_t *data, const TwPair<uint64_t> *tw, const ModParams<uint64_t> &P,
                          uint32_t nsub, hipStream_t stream);
+template <int CLS>
 hipError_t launch_mul_ntt_fp(int logn, uint64_t *lhs, const uint64_t *rhs_ntt, const TwPair<uint64_t> *twf,
                              const TwPair<uint64_t> *twi, const ModParams<uint64_t> &P, uint32_t nsub, hipStream_t stream);
 

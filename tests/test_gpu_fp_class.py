@@ -1,6 +1,6 @@
-"""CLS_FP (64-bit words, p < 2^50: residues held as exact integers in doubles, v_fma_f64 butterflies -- the device
-counterpart of the reference's src/prime64/less_than_50bit.rs class): bit-exact parity with the oracle's integer
-arithmetic on every LDS-resident size, at the edges of the magnitude bounds the kernel relies on (all-(p-1) inputs, the
+"""CLS_FP / CLS_FP51 (64-bit words, p < 2^50 / p < 2^51: residues held as exact integers in doubles, v_fma_f64
+butterflies -- the device counterparts of the reference's src/prime64/less_than_50bit.rs and less_than_51bit.rs
+classes): bit-exact parity with the oracle's integer arithmetic on every LDS-resident size, at the edges of the magnitude bounds the kernel relies on (all-(p-1) inputs, the
 largest admissible primes), through the fused product and the fused mul_accumulate chains, and against the same plan
 forced onto the integer butterflies."""
 import os
@@ -16,6 +16,7 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P50 = 1125899904679937            # benches/ntt.rs:112: largest prime = 1 mod 2^16 below 2^50
+P51 = 2251799813554177            # benches/ntt.rs:113: ... below 2^51
 PRIMES52 = [1125899881086977, 1125899885412353, 1125899886395393, 1125899899174913, 1125899902124033,
             1125899903107073]     # src/lib.rs:601-606
 
@@ -62,12 +63,13 @@ def check_transforms(oracle, n, p, seed):
     return plan
 
 
+@pytest.mark.parametrize("p,cls", [(P50, 3), (P51, 4)])
 @pytest.mark.parametrize("logn", list(range(4, 16)))
-def test_fp_every_size_vs_oracle(oracle, logn):
-    """N = 16 ... 16384 run in CLS_FP (arith_class 3); N = 32768 falls back to the integer global-stage path."""
+def test_fp_every_size_vs_oracle(oracle, logn, p, cls):
+    """N = 16 ... 16384 run in CLS_FP / CLS_FP51 (arith_class 3 / 4); N = 32768 falls back to the integer global-stage path."""
     n = 1 << logn
-    plan = check_transforms(oracle, n, P50, 4000 + logn)
-    assert plan.info().arith_class == (3 if logn <= 14 else 0)
+    plan = check_transforms(oracle, n, p, 4000 + logn)
+    assert plan.info().arith_class == (cls if logn <= 14 else 0)
 
 
 @pytest.mark.parametrize("p", PRIMES52 + [65537, 786433, "40-bit", "49-bit"])
@@ -84,17 +86,22 @@ def test_fp_other_primes(oracle, p):
 
 
 def test_fp_class_boundary(oracle):
-    """p just below 2^50 uses CLS_FP; the first prime above 2^50 (51-bit class of the reference) does not."""
+    """The largest admissible primes of both classes (least headroom below 2^53), and the first class above."""
     lo = oracle.largest_prime_in_arithmetic_progression64(1 << 12, 1, 1 << 49, 1 << 50)
     assert (1 << 50) - lo < (1 << 24)
-    plan = check_transforms(oracle, 2048, lo, 77)
-    assert plan.info().arith_class == 3
-    hi = 2251799813554177          # benches/ntt.rs:113, 51-bit
+    for n in (64, 2048):
+        assert check_transforms(oracle, n, lo, 77).info().arith_class == 3
+    mid = oracle.largest_prime_in_arithmetic_progression64(1 << 12, 1, 1 << 50, 1 << 51)
+    assert (1 << 51) - mid < (1 << 24)
+    for n in (64, 2048):
+        assert check_transforms(oracle, n, mid, 78).info().arith_class == 4
+    hi = oracle.largest_prime_in_arithmetic_progression64(1 << 12, 1, 1 << 51, 1 << 52)
     assert prime64.Plan.try_new(1024, hi).info().arith_class == 0
 
 
+@pytest.mark.parametrize("P50", [P50, P51])
 @pytest.mark.parametrize("n", [16, 32, 256, 1024, 2048, 4096])
-def test_fp_fused_product_equals_three_calls(oracle, n):
+def test_fp_fused_product_equals_three_calls(oracle, n, P50):
     plan, ref = prime64.Plan.try_new(n, P50), oracle.Plan.try_new(n, P50, 64)
     for batch in (1, 13, 301):
         a = oracle.fill_uniform(batch * n, P50, 31 + batch, 64)
@@ -117,10 +124,10 @@ def test_fp_fused_product_equals_three_calls(oracle, n):
 
 @pytest.mark.parametrize("n,J,O,batch", [(1024, 6, 2, 5), (1024, 17, 1, 3), (2048, 9, 3, 2), (256, 25, 4, 7), (64, 8, 2, 9)])
 @pytest.mark.parametrize("accumulate", [False, True])
-def test_fp_mul_accumulate_chain(oracle, n, J, O, batch, accumulate):
+@pytest.mark.parametrize("p", [P50, P51])
+def test_fp_mul_accumulate_chain(oracle, n, J, O, batch, accumulate, p):
     """out[b][o] (+)= inv(sum_j fwd(terms[b][j]) . key[j][o]) in the fused chain kernel: more than eight terms exercise
     the accumulator's range reduction; the first element is the extreme one (every word p-1)."""
-    p = P50
     plan, ref = prime64.Plan.try_new(n, p), oracle.Plan.try_new(n, p, 64)
     terms = oracle.fill_uniform(batch * J * n, p, 11 + n, 64)
     key = oracle.fill_uniform(J * O * n, p, 22 + n, 64)
@@ -143,7 +150,8 @@ def test_fp_mul_accumulate_chain(oracle, n, J, O, batch, accumulate):
     assert np.array_equal(to_host(dout), want.astype(np.uint64))
 
 
-def test_fp_equals_integer_butterflies_on_a_large_batch():
+@pytest.mark.parametrize("P50,cls", [(P50, "3"), (P51, "4")])
+def test_fp_equals_integer_butterflies_on_a_large_batch(P50, cls):
     """The same plan with CNTT_DISABLE_FP=1 (integer Shoup butterflies) in a child process: identical bytes for fwd, inv
     and the fused product on 4096 random polynomials (a size the oracle would take long for is not needed: this is a
     device-vs-device check of two independent arithmetic paths)."""
@@ -168,5 +176,5 @@ print(*out)
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         res.append(r.stdout.split())
-    assert res[0][0] == "3" and res[1][0] == "0"
+    assert res[0][0] == cls and res[1][0] == "0"
     assert res[0][1:] == res[1][1:]

@@ -56,6 +56,7 @@ def test_plans_match_golden(golden):
 
 @pytest.mark.parametrize("bits,n,p", [(64, 4096, 4611686018427322369), (64, 2048, 18446744069414584321),
                                       (64, 1024, 1125899904679937), (64, 32768, 1125899904679937),
+                                      (64, 2048, 2251799813554177),
                                       (64, 512, 9223372036853661697), (32, 8192, 1073479681),
                                       (32, 256, 4293918721), (32, 2048, 2147352577)])
 def test_plans_match_oracle(oracle, bits, n, p):
@@ -72,8 +73,8 @@ def test_plans_match_oracle(oracle, bits, n, p):
     if info.has_shoup:
         assert (info.n_inv_mod_p_shoup, info.p_barrett) == (ref.n_inv_mod_p_shoup, ref.p_barrett)
     expect_cls = 0 if p < (1 << (bits - 2)) else (1 if p < (1 << (bits - 1)) else 2)
-    if bits == 64 and p < (1 << 50) and n <= 16384:
-        expect_cls = 3   # double-precision FMA butterflies (csrc/ntt_arith.hpp, CLS_FP)
+    if bits == 64 and p < (1 << 51) and n <= 16384:
+        expect_cls = 3 if p < (1 << 50) else 4   # double-precision FMA butterflies (csrc/ntt_arith.hpp, CLS_FP / CLS_FP51)
     assert info.arith_class == expect_cls
 
 

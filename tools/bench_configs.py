@@ -175,6 +175,10 @@ if __name__ == "__main__":
         prime_case(prime64, 64, 2048, P50, 32768, "prime64 50-bit")
         prime_case(prime64, 64, 4096, P50, 16384, "prime64 50-bit")
         prime_case(prime64, 64, 16384, P50, 4096, "prime64 50-bit")
+    if "fp51" in which:   # CLS_FP51: the 51-bit bench prime of benches/ntt.rs:113
+        P51 = 2251799813554177
+        for n, b in ((1024, 65536), (4096, 16384), (16384, 4096)):
+            prime_case(prime64, 64, n, P51, b, "prime64 51-bit")
     if "p64n2048" in which:
         prime_case(prime64, 64, 2048, P62, 32768, "prime64")
     if "c3" in which:
