@@ -203,15 +203,15 @@ class Timer:
 
 
 def pmc_traffic(kernel_key, batch):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes of THIS build (FETCH_SIZE doubled for gfx950 +
-    WRITE_SIZE, MI355X_MICROARCH.md section HBM); None when no such profile is committed for the kernel/batch."""
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes of THIS build (profiles/pmc_traffic.json, written
+    by tools/profile.sh: FETCH_SIZE doubled for gfx950 + WRITE_SIZE, MI355X_MICROARCH.md section HBM).  The passes run
+    the kernel at the bench's own shape (batch 65536); None for any other batch or when no profile is committed."""
+    if batch != 65536:
+        return None, None
     try:
         with open(PMC_FILE) as f:
-            table = json.load(f)
-        e = table[kernel_key]
-        if int(e["batch"]) != int(batch):
-            return None, None
-        return float(e["hbm_bytes_per_launch"]), e.get("source")
+            e = json.load(f)[kernel_key]
+        return float(e["hbm_bytes_per_launch"]), "profiles/pmc_traffic.json: " + e.get("source", "rocprofv3 --pmc")
     except (OSError, KeyError, ValueError, TypeError):
         return None, None
 
@@ -444,7 +444,7 @@ def run_rank(args):
     fused_alg = 2 * alg_bytes
     achieved = fused_alg / (fused_ms * 1e-3) / 1e9
     moved = 3 * N * 8 * batch
-    traffic, traffic_src = pmc_traffic("mul_kernel_wp_u64_logn10_lazy", batch)
+    traffic, traffic_src = pmc_traffic("mul_kernel_wp<u64, 10, 0, 768, 3>", batch)
 
     extras = []
     try:

@@ -337,11 +337,11 @@ struct NttKernel {
             }
             return;
         }
-        // Twiddles of the stage, TWC at a time: all NHI at once when they come from LDS or scalar loads; kernels that
-        // read thread-dependent twiddles from global memory (TWC > 0) bound the registers those loads hold.
+        // Twiddles of the stage, TWC at a time (TWC = 0: all NHI at once): bounds the registers the thread-dependent
+        // twiddle loads hold (global-memory twiddles of the large sizes; workgroup shapes compiled for 128 VGPRs).
         constexpr StageGeom g = geom(K, GI);
         constexpr bool UNI = g.uniform && !SUB;
-        constexpr bool CHUNKED = TWC > 0 && !UNI && !(IMG && !g.uniform) && NHI > TWC;
+        constexpr bool CHUNKED = TWC > 0 && !UNI && NHI > TWC;
         constexpr int CH = CHUNKED ? TWC : NHI;
 #pragma unroll
         for (int h0 = 0; h0 < NHI; h0 += CH) {
@@ -500,7 +500,7 @@ struct NttWp : NttKernel<T, LOGN, INV, CLS, false, FAM> {
 
     // USE_IMG = false: no LDS twiddle image (sizes whose image does not fit next to the exchange buffer): the
     // thread-dependent twiddles are read from the table in global memory (L2) inside the passes.
-    template <bool USE_IMG = true>
+    template <bool USE_IMG = true, int TWC_IMG = 0>
     static __device__ __forceinline__ void run(T *__restrict__ data, const TwPair<T> *__restrict__ tw,
                                                const ModParams<T> &P, uint32_t nsub, T *lds_all, TwPair<T> *img) {
         if constexpr (USE_IMG) {
@@ -531,14 +531,15 @@ struct NttWp : NttKernel<T, LOGN, INV, CLS, false, FAM> {
             const uint32_t tnext = tile + gridDim.x;
             const bool more = tnext < ntiles;  // workgroup-uniform
             T *tbase = data + (((size_t)tile * PPB) << LOGN);
-            // Without the image every address of the tile body (layout offsets, twiddle table offsets) is recomputed
-            // per tile from an opaque copy of the thread index: left to itself hipcc hoists all of them out of the
-            // tile loop and then spills the lot.
+            // In the shapes compiled for 128 VGPRs every address of the tile body (layout offsets, twiddle offsets) is
+            // recomputed per tile from an opaque copy of the thread index: left to itself hipcc hoists all of them out
+            // of the tile loop and then spills the lot.
+            constexpr bool RECOMPUTE = !USE_IMG || TWC_IMG > 0;  // the shapes compiled for 128 VGPRs
             uint32_t tidv = tid;
-            if constexpr (!USE_IMG) asm volatile("" : "+v"(tidv));
-            const uint32_t eb0 = USE_IMG ? ebase0 : pdep<CM0>(tidv), ebL = USE_IMG ? ebaseL : pdep<CML>(tidv);
-            const uint32_t ebIO = USE_IMG ? ebaseIO : pdep<CMIO>(tidv);
-            const uint32_t voff = USE_IMG ? voffIO : ((pl << LOGN) + ebIO) * (uint32_t)sizeof(T);
+            if constexpr (RECOMPUTE) asm volatile("" : "+v"(tidv));
+            const uint32_t eb0 = RECOMPUTE ? pdep<CM0>(tidv) : ebase0, ebL = RECOMPUTE ? pdep<CML>(tidv) : ebaseL;
+            const uint32_t ebIO = RECOMPUTE ? pdep<CMIO>(tidv) : ebaseIO;
+            const uint32_t voff = RECOMPUTE ? ((pl << LOGN) + ebIO) * (uint32_t)sizeof(T) : voffIO;
             typename B::AsyncVec vn[E / B::MAXV];
             if (more) {
                 // ragged tail: lanes of polynomials past the end re-read the last polynomial (harmless, in range)
@@ -555,7 +556,7 @@ struct NttWp : NttKernel<T, LOGN, INV, CLS, false, FAM> {
                 B::template gather<RM0>(r, (const T *)lds, eb0, true);
                 wsync();
             }
-            pass<0, false, USE_IMG, true, USE_IMG ? 0 : 2>(r, lds, tidv, tw, img, P);
+            pass<0, false, USE_IMG, true, USE_IMG ? TWC_IMG : 2>(r, lds, tidv, tw, img, P);
             if constexpr (RML != IO_RM) {  // output transpose
                 wsync();
                 B::template scatter<RML>(r, lds, ebL, true);

@@ -79,14 +79,14 @@ template <bool INV> __global__ __launch_bounds__(256) void lab_alu_only(uint64_t
     if (acc == 0x1234567ull) sink[0] = acc;
     st.end();
 }
-template <bool INV, int WPB, int WPW> __global__ __launch_bounds__(WPB, WPW) void lab_wp_stamped(
+template <bool INV, int WPB, int WPW, int TWC = 0> __global__ __launch_bounds__(WPB, WPW) void lab_wp_stamped(
     uint64_t *data, const TwPair<uint64_t> *tw, const ModParams<uint64_t> P, uint32_t nsub) {
     using K = NttWp<uint64_t, 10, INV, CLS_LAZY, WPB>;
     __shared__ __attribute__((aligned(16))) uint64_t lds[(size_t)K::PPB << 10];
     __shared__ __attribute__((aligned(16))) TwPair<uint64_t> img[K::B::IMG_ENTRIES];
     LabStamp st;
     st.begin();
-    K::run(data, tw, P, nsub, lds, img);
+    K::template run<true, TWC>(data, tw, P, nsub, lds, img);
     st.end();
 }
 
@@ -139,13 +139,13 @@ template <bool INV> static void alu_only(const char *name) {
     const uint32_t grid = BATCH / (256 / K::TPP);  // as many threads as the real transform of the batch
     timeit(name, [&] { hipLaunchKernelGGL((lab_alu_only<INV>), dim3(grid), dim3(256), 0, 0, g_data, g_tw, g_P); });
 }
-template <int WPB, int WPW, bool INV> static void wp_stamped(const char *name, int blocks_per_cu) {
+template <int WPB, int WPW, bool INV, int TWC = 0> static void wp_stamped(const char *name, int blocks_per_cu) {
     using K = NttWp<uint64_t, 10, INV, CLS_LAZY, WPB>;
     const uint32_t ntiles = (BATCH + K::PPB - 1) / K::PPB;
     uint32_t grid = 256u * (uint32_t)blocks_per_cu;
     if (grid > ntiles) grid = ntiles;
     timeit(name, [&] {
-        hipLaunchKernelGGL((lab_wp_stamped<INV, WPB, WPW>), dim3(grid), dim3(WPB), 0, 0, g_data, g_tw, g_P, BATCH);
+        hipLaunchKernelGGL((lab_wp_stamped<INV, WPB, WPW, TWC>), dim3(grid), dim3(WPB), 0, 0, g_data, g_tw, g_P, BATCH);
     });
 }
 
@@ -205,5 +205,11 @@ int main() {
     wp_stamped<256, LAB_WPW, false>("fwd wp stamped, 3 WG/CU", 3);
     wp_stamped<256, LAB_WPW, false>("fwd wp stamped, 2 WG/CU", 2);
     wp_stamped<256, LAB_WPW, true>("inv wp stamped, 3 WG/CU", 3);
+    // four waves per SIMD (128 VGPRs): twiddle image reads in chunks of 2 / 4 pairs
+    wp_stamped<1024, 4, false, 2>("fwd wp 1024thr x1/CU, TWC=2", 1);
+    wp_stamped<1024, 4, false, 4>("fwd wp 1024thr x1/CU, TWC=4", 1);
+    wp_stamped<512, 4, false, 2>("fwd wp 512thr x2/CU, TWC=2", 2);
+    wp_stamped<1024, 4, true, 2>("inv wp 1024thr x1/CU, TWC=2", 1);
+    wp_stamped<256, 3, false, 4>("fwd wp 256thr x3/CU, TWC=4", 3);
     return 0;
 }
