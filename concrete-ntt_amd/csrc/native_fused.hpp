@@ -1,11 +1,13 @@
 // Whole negacyclic_polymul of the native / native_binary Plan32 kinds in ONE kernel: for every
 // prime  split(lhs), split(rhs) -> two forward transforms -> pointwise product -> inverse transform (1/N folded into
 // its last stage)  with the residues kept in registers, then the mixed-radix CRT on the register tiles and one store
-// of the product word.  HBM traffic per product: lhs + rhs read, prod written (the fused lower bound of SURVEY 8(d));
-// the unfused pipeline moves the 2k residue arrays through HBM several times.
+// of the product word.  HBM traffic per product: lhs + rhs read ONCE (kept in registers across the primes), prod
+// written (the fused lower bound of SURVEY 8(d)); the unfused pipeline moves the 2k residue arrays through HBM
+// several times.
 // Values are those of src/native64.rs:1042-1069 (and siblings): same split (% P_i), same transforms, same digits.
 // Twiddles come from the per-prime tables in global memory (L2): an LDS image per prime would not fit.
 #pragma once
+#include <type_traits>
 #include "aux_kernels.hpp"
 #include "ntt_kernel.hpp"
 
@@ -174,22 +176,33 @@ __global__ __launch_bounds__(BLK, 2) void native_polymul_kernel(typename NativeS
     const W *lp = lhs + ((size_t)subc << LOGN), *rp = rhs + ((size_t)subc << LOGN);
     const uint32_t ebase = pdep<FULL & ~RM0>(tid);
     uint32_t res[KP - PARK][E];
+    // Both operands are read ONCE and stay in registers for all KP primes (a re-read per prime came back from HBM
+    // more often than not: rocprofv3 FETCH_SIZE showed 2.9x the operand bytes for native64 N=4096 -- profiles/r02).
+    W lw[E];
+    typename std::conditional<SH::BINARY, uint32_t, W>::type rw[E];
+#pragma unroll
+    for (int j = 0; j < E; ++j) lw[j] = lp[ebase | cdep((uint32_t)j, RM0)];
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        const W w = rp[ebase | cdep((uint32_t)j, RM0)];
+        if constexpr (SH::BINARY) {  // `as u32`: src/native_binary64.rs:379-385, src/native_binary128.rs:100-106
+            if constexpr (sizeof(W) == 16) rw[j] = (uint32_t)w.lo;
+            else rw[j] = (uint32_t)w;
+        } else {
+            rw[j] = w;
+        }
+    }
     static_for<0, KP>([&](auto ic) {
         constexpr int i = ic.value;
         uint32_t a[E], b[E];
 #pragma unroll
-        for (int j = 0; j < E; ++j) a[j] = split30<W>(lp[ebase | cdep((uint32_t)j, RM0)], S, i);
+        for (int j = 0; j < E; ++j) a[j] = split30<W>(lw[j], S, i);
         Wf::template pass<0, false, false>(a, lds, tid, F.twf[i], nullptr, F.P[i]);
         Wf::wsync();
 #pragma unroll
         for (int j = 0; j < E; ++j) {
-            const W w = rp[ebase | cdep((uint32_t)j, RM0)];
-            if constexpr (SH::BINARY) {  // `as u32`: src/native_binary64.rs:379-385, src/native_binary128.rs:100-106
-                if constexpr (sizeof(W) == 16) b[j] = (uint32_t)w.lo;
-                else b[j] = (uint32_t)w;
-            } else {
-                b[j] = split30<W>(w, S, i);
-            }
+            if constexpr (SH::BINARY) b[j] = rw[j];
+            else b[j] = split30<W>(rw[j], S, i);
         }
         Wf::template pass<0, false, false>(b, lds, tid, F.twf[i], nullptr, F.P[i]);
 #pragma unroll
