@@ -63,7 +63,8 @@ static inline unsigned ew_grid(size_t work_items) {
 // ---------------------------------------------------------------------------------------------
 template <class T> struct DeviceTables {
     TwPair<T> *fwd = nullptr, *inv = nullptr;
-    // CLS_FP plans only: the same twiddles as (c, c / p) doubles, c centred in (-p/2, p/2]
+    // plans whose LDS-resident transforms run in a 64-bit-only class: the same twiddles in that class's form --
+    // CLS_FP / CLS_FP51: (c, c / p) doubles, c centred in (-p/2, p/2];  CLS_PM64: plain residues
     TwPair<T> *fwd_fp = nullptr, *inv_fp = nullptr;
 };
 
@@ -205,14 +206,31 @@ template <class T, class PlanT> static int plan_new(size_t n, T p, PlanT **out) 
             mp.fp_last_w_q = host::double_bits(wl / pd);
         }
     }
+    // CLS_PM64: p = 2^64 - c with c < 2^32 (Solinas, and the largest primes below 2^64).  CNTT_DISABLE_PM64=1 keeps the
+    // Montgomery class (A/B measurements and tests).
+    mp.pm_c = 0;
+    if constexpr (B == 64) {
+        const char *off = std::getenv("CNTT_DISABLE_PM64");
+        const uint64_t c = (uint64_t)0 - p64;
+        if (p64 >= ((uint64_t)1 << 63) && c < ((uint64_t)1 << 32) && !(off && off[0] == '1')) {
+            mp.pm_c = (uint32_t)c;
+            mp.pm_n_inv = pl->n_inv;
+            mp.pm_last_w = (T)w_last;
+        }
+    }
     pl->cache = std::make_shared<DeviceCache<T>>();
     *out = pl;
     return CNTT_OK;
 }
 
+static bool alt_tables(int cls) { return is_fp_class(cls) || cls == CLS_PM64; }
+
 // transform class of the LDS-resident kernels for this plan (the global-stage path of larger sizes is integer-only)
 template <class T> static int transform_class(const PrimePlan<T> *pl) {
-    return (pl->mp.fp && pl->logn <= MaxLdsLogN<T>::value) ? (int)pl->mp.fp : (int)pl->mp.cls;
+    if (pl->logn > MaxLdsLogN<T>::value) return (int)pl->mp.cls;
+    if (pl->mp.fp) return (int)pl->mp.fp;
+    if (pl->mp.pm_c) return (int)CLS_PM64;
+    return (int)pl->mp.cls;
 }
 
 // per-device table replica, created on first use under the cache mutex
@@ -251,14 +269,21 @@ template <class T> static int device_tables(const PrimePlan<T> *pl, DeviceTables
     HIP_TRY(hipMemcpy(t.fwd, f.data(), n * sizeof(TwPair<T>), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(t.inv, i.data(), n * sizeof(TwPair<T>), hipMemcpyHostToDevice));
     if constexpr (sizeof(T) == 8) {
-        if (pl->mp.fp) {
+        if (pl->mp.fp || pl->mp.pm_c) {
             const double pd = (double)p64;
             for (size_t k = 0; k < n; ++k) {
-                const double cf = host::centred((uint64_t)pl->twid[k], p64), ci = host::centred((uint64_t)pl->inv_twid[k], p64);
-                f[k].w = host::double_bits(cf);
-                f[k].ws = host::double_bits(cf / pd);
-                i[k].w = host::double_bits(ci);
-                i[k].ws = host::double_bits(ci / pd);
+                if (pl->mp.fp) {
+                    const double cf = host::centred((uint64_t)pl->twid[k], p64), ci = host::centred((uint64_t)pl->inv_twid[k], p64);
+                    f[k].w = host::double_bits(cf);
+                    f[k].ws = host::double_bits(cf / pd);
+                    i[k].w = host::double_bits(ci);
+                    i[k].ws = host::double_bits(ci / pd);
+                } else {
+                    f[k].w = pl->twid[k];
+                    f[k].ws = 0;
+                    i[k].w = pl->inv_twid[k];
+                    i[k].ws = 0;
+                }
             }
             if (hipMalloc((void **)&t.fwd_fp, n * sizeof(TwPair<T>)) != hipSuccess ||
                 hipMalloc((void **)&t.inv_fp, n * sizeof(TwPair<T>)) != hipSuccess) {
@@ -307,9 +332,9 @@ template <class T> static int ntt_device(const PrimePlan<T> *pl, T *d, size_t ba
     hipError_t e;
     if (!inv) {
         for (int s = 0; s < depth; ++s) global_stage<T, false>(d, t.fwd, pl->mp, (uint32_t)pl->logn, (uint32_t)s, nbfly, false, st);
-        e = launch_ntt<T, false>(sub_logn, tcls, d, is_fp_class(tcls) ? t.fwd_fp : t.fwd, pl->mp, nsub, (uint32_t)depth, st);
+        e = launch_ntt<T, false>(sub_logn, tcls, d, alt_tables(tcls) ? t.fwd_fp : t.fwd, pl->mp, nsub, (uint32_t)depth, st);
     } else {
-        e = launch_ntt<T, true>(sub_logn, tcls, d, is_fp_class(tcls) ? t.inv_fp : t.inv, pl->mp, nsub, (uint32_t)depth, st);
+        e = launch_ntt<T, true>(sub_logn, tcls, d, alt_tables(tcls) ? t.inv_fp : t.inv, pl->mp, nsub, (uint32_t)depth, st);
         for (int s = depth - 1; s >= 0 && e == hipSuccess; --s)
             global_stage<T, true>(d, t.inv, pl->mp, (uint32_t)pl->logn, (uint32_t)s, nbfly, s == 0, st);
     }
@@ -349,8 +374,8 @@ template <class T> static int mul_ntt_device(const PrimePlan<T> *pl, T *lhs, con
     DeviceTables<T> t;
     if (int rc = device_tables(pl, &t)) return rc;
     const int tcls = transform_class(pl);
-    const hipError_t e = launch_mul_ntt<T>(pl->logn, tcls, lhs, rhs, is_fp_class(tcls) ? t.fwd_fp : t.fwd,
-                                           is_fp_class(tcls) ? t.inv_fp : t.inv, pl->mp, (uint32_t)batch, st);
+    const hipError_t e = launch_mul_ntt<T>(pl->logn, tcls, lhs, rhs, alt_tables(tcls) ? t.fwd_fp : t.fwd,
+                                           alt_tables(tcls) ? t.inv_fp : t.inv, pl->mp, (uint32_t)batch, st);
     if (e == hipSuccess) return CNTT_OK;
     if (e != hipErrorNotSupported) return fail(CNTT_EDEVICE, "fused product launch failed: %s", hipGetErrorString(e));
     (void)hipGetLastError();
@@ -375,8 +400,8 @@ static int external_product_device(const PrimePlan<T> *pl, T *out, const T *term
     DeviceTables<T> t;
     if (int rc = device_tables(pl, &t)) return rc;
     const int tcls = transform_class(pl);
-    const hipError_t e = launch_ext_ntt<T>(pl->logn, tcls, out, terms, key, is_fp_class(tcls) ? t.fwd_fp : t.fwd,
-                                           is_fp_class(tcls) ? t.inv_fp : t.inv, pl->mp, (uint32_t)batch, (uint32_t)nterms,
+    const hipError_t e = launch_ext_ntt<T>(pl->logn, tcls, out, terms, key, alt_tables(tcls) ? t.fwd_fp : t.fwd,
+                                           alt_tables(tcls) ? t.inv_fp : t.inv, pl->mp, (uint32_t)batch, (uint32_t)nterms,
                                            (uint32_t)nout, accumulate, st);
     if (e == hipSuccess) return CNTT_OK;
     if (e != hipErrorNotSupported) return fail(CNTT_EDEVICE, "fused mul_accumulate chain launch failed: %s", hipGetErrorString(e));

@@ -15,6 +15,9 @@
 //               integer representative |v| < 2^53 and multiply with v_fma_f64 -- on gfx950 a double FMA
 //               issues at the rate of ONE 32-bit integer multiply, and an exact 50 x 53-bit modular product
 //               is six of them instead of ten integer multiplies and their carry chains (see BflyFp).
+//   CLS_PM64    64-bit words, p = 2^64 - c with c < 2^32: the Solinas prime 2^64 - 2^32 + 1 (src/prime64/
+//               generic_solinas.rs:35-40,102-128) and every "largest prime below 2^64" of the reference's benches.
+//               2^64 = c (mod p) folds a 128-bit product in two multiply-adds instead of a Montgomery reduction.
 //   CLS_FP51    the same for 2^50 <= p < 2^51 (src/prime64/less_than_51bit.rs): 2^53 is only 4p there, so the range
 //               reductions come more often.
 #pragma once
@@ -23,7 +26,7 @@
 
 namespace cntt {
 
-enum : int { CLS_LAZY = 0, CLS_STRICT = 1, CLS_GENERIC = 2, CLS_FP = 3, CLS_FP51 = 4 };
+enum : int { CLS_LAZY = 0, CLS_STRICT = 1, CLS_GENERIC = 2, CLS_FP = 3, CLS_FP51 = 4, CLS_PM64 = 5 };
 
 // One table entry: the twiddle and its Shoup companion floor(w * 2^B / p) (CLS_GENERIC: w holds
 // w * 2^B mod p and ws is unused).  Interleaved so that one 16-byte (u64) / 8-byte (u32) load
@@ -50,6 +53,9 @@ template <class T> struct ModParams {
     uint32_t big_q;        // floor(log2 p) + 1
     uint32_t cls;          // integer arithmetic class (pointwise kernels, global stages, every non-FP transform)
     uint32_t fp;           // CLS_FP / CLS_FP51: class of the LDS-resident transforms of this plan (0: cls)
+    // CLS_PM64 (p = 2^64 - c, c < 2^32): c, and the plan constants as plain residues
+    uint32_t pm_c;         // 0: not such a modulus
+    T pm_n_inv, pm_last_w;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -249,6 +255,7 @@ template <class T, int CLS> struct Bfly {
         }
     }
     static constexpr bool IS_FP = false;
+    static constexpr bool FUSED_LAZY = false;  // the fused kernels hand canonical values to the pointwise product
     // a word as loaded from memory -> the class's register form (identity for the integer classes)
     static __device__ __forceinline__ T load_fix(T v) { return v; }
     static __device__ __forceinline__ T reduce(T v, const ModParams<T> &) { return v; }
@@ -325,6 +332,7 @@ struct Fp {
 template <class T, int HEAD> struct BflyFp {
     static_assert(sizeof(T) == 8, "the double-precision classes are 64-bit classes");
     static constexpr bool IS_FP = true;
+    static constexpr bool FUSED_LAZY = true;   // mul_for_inv / mul_acc_cls take the lazy doubles
     static constexpr int FWD_REDUCE_EVERY = HEAD >= 8 ? 5 : 3;   // forward: every value, after this many stages
     static constexpr int INV_REDUCE_EVERY = HEAD >= 8 ? 2 : 1;   // inverse: the sums, after this many stages
     static constexpr int ACC_REDUCE_EVERY = HEAD >= 8 ? 8 : 2;   // mul_accumulate chains: products (<= 0.875 p) per reduction
@@ -358,6 +366,107 @@ template <class T, int HEAD> struct BflyFp {
 template <class T> struct Bfly<T, CLS_FP> : BflyFp<T, 8> {};
 template <class T> struct Bfly<T, CLS_FP51> : BflyFp<T, 4> {};
 __host__ __device__ constexpr bool is_fp_class(int cls) { return cls == CLS_FP || cls == CLS_FP51; }
+
+// ---------------------------------------------------------------------------------------------
+// CLS_PM64: p = 2^64 - c, c < 2^32 (64-bit words)
+//
+// Registers hold ANY representative in [0, 2^64) of a residue; products by a canonical factor come out canonical.
+//   product   y w = H 2^64 + L (the carry-out trick of shoup_core gives H; L = lo32(y0 w0) | lo32(...) << 32)
+//             = L + H c                      (2^64 = c)
+//             = L + H0 c + (H1 c) 2^32       three 32-bit limbs and a top word  top = hi32(H1 c) + carries <= c + 1
+//             = (limbs) + top c              one more multiply-add, at most one further carry (+ c)
+//             w < p bounds H <= p - 2, which keeps `top` inside 32 bits even for c = 2^32 - 1 (then H1 <= 2^32 - 2).
+//   sum / difference with a canonical second operand: one wrap at most, corrected by +-c (2^64 = c); with two
+//             arbitrary representatives a second wrap is possible and corrected the same way.
+// The reference computes exact `%` products here (src/prime64/generic_solinas.rs:42-128): same residues.
+// One inline-asm block (fixed scratch v[2:7], two wait states behind every VALU-written SGPR, see shoup_core).
+// ---------------------------------------------------------------------------------------------
+#define CNTT_PM_BODY                                          \
+    "v_mad_u64_u32 v[2:3], %[k], %[y0], %[w1], %[u]\n\t"      \
+    "v_mul_lo_u32 v6, %[y0], %[w0]\n\t"                       \
+    "v_mov_b32 v7, v2\n\t"                                    \
+    "v_mov_b32 v2, v3\n\t"                                    \
+    "v_cndmask_b32_e64 v3, 0, 1, %[k]\n\t"                    \
+    "v_mad_u64_u32 v[2:3], vcc, %[y1], %[w1], v[2:3]\n\t"     \
+    "v_mad_u64_u32 v[6:7], %[k], v2, %[c], v[6:7]\n\t"        \
+    "v_mad_u64_u32 v[4:5], vcc, v3, %[c], 0\n\t"              \
+    "v_add_co_u32 v7, vcc, v7, v4\n\t"                        \
+    "s_nop 1\n\t"                                             \
+    "v_addc_co_u32 v5, vcc, 0, v5, vcc\n\t"                   \
+    "v_addc_co_u32_e64 v5, vcc, v5, 0, %[k]\n\t"              \
+    "v_mad_u64_u32 v[6:7], %[k], v5, %[c], v[6:7]\n\t"        \
+    "s_nop 1\n\t"                                             \
+    "v_cndmask_b32_e64 v4, 0, 1, %[k]\n\t"                    \
+    "v_mad_u64_u32 v[6:7], vcc, v4, %[c], v[6:7]"
+
+// y * w mod (2^64 - c) for any y < 2^64 and w < p: some representative in [0, 2^64)
+template <bool UNI> __device__ __forceinline__ uint64_t pm_mul_lazy(uint64_t y, uint64_t w, uint32_t c) {
+    const uint32_t y0 = (uint32_t)y, y1 = (uint32_t)(y >> 32);
+    const uint32_t w0 = (uint32_t)w, w1 = (uint32_t)(w >> 32);
+    const uint64_t t = __umulhi(y0, w0);
+    const uint64_t u = (uint64_t)y1 * w0 + t;  // cannot overflow
+    uint64_t out, ck;
+    if constexpr (UNI)
+        asm(CNTT_PM_BODY : "=&{v[6:7]}"(out), [k] "=&s"(ck)
+            : [y0] "v"(y0), [y1] "v"(y1), [w0] "s"(w0), [w1] "s"(w1), [c] "s"(c), [u] "v"(u)
+            : "vcc", "v2", "v3", "v4", "v5");
+    else
+        asm(CNTT_PM_BODY : "=&{v[6:7]}"(out), [k] "=&s"(ck)
+            : [y0] "v"(y0), [y1] "v"(y1), [w0] "v"(w0), [w1] "v"(w1), [c] "s"(c), [u] "v"(u)
+            : "vcc", "v2", "v3", "v4", "v5");
+    return out;
+}
+
+template <class T> struct Bfly<T, CLS_PM64> {
+    static_assert(sizeof(T) == 8, "CLS_PM64 is a 64-bit class");
+    static constexpr bool IS_FP = false;
+    static constexpr bool FUSED_LAZY = true;  // products take any representative: fused kernels skip finish_fwd
+    static __device__ __forceinline__ T load_fix(T v) { return v; }
+    static __device__ __forceinline__ T reduce(T v, const ModParams<T> &) { return v; }
+    static __device__ __forceinline__ T canon(T v, const ModParams<T> &P) { return v >= P.p ? v + P.pm_c : v; }  // v - p
+    template <bool UNI> static __device__ __forceinline__ T mulc(T y, T w, const ModParams<T> &P) {
+        return canon(pm_mul_lazy<UNI>(y, w, P.pm_c), P);
+    }
+    // x + t, x - t for any x and canonical t
+    static __device__ __forceinline__ T add_c(T x, T t, const ModParams<T> &P) {
+        const T s = x + t;
+        return s + (s < x ? (T)P.pm_c : (T)0);
+    }
+    static __device__ __forceinline__ T sub_c(T x, T t, const ModParams<T> &P) {
+        const T d = x - t;
+        return d - (x < t ? (T)P.pm_c : (T)0);
+    }
+    // x + y, x - y for any two representatives
+    static __device__ __forceinline__ T add_full(T x, T y, const ModParams<T> &P) {
+        const T s = x + y;
+        const T s2 = s + (s < x ? (T)P.pm_c : (T)0);
+        return s2 + (s2 < s ? (T)P.pm_c : (T)0);
+    }
+    static __device__ __forceinline__ T sub_full(T x, T y, const ModParams<T> &P) {
+        const T d = x - y;
+        const T d2 = d - (x < y ? (T)P.pm_c : (T)0);
+        return d2 - (d2 > d ? (T)P.pm_c : (T)0);
+    }
+    template <bool UNI = false>
+    static __device__ __forceinline__ void fwd(T &x, T &y, T w, T, const ModParams<T> &P) {
+        const T t = mulc<UNI>(y, w, P);
+        y = sub_c(x, t, P);
+        x = add_c(x, t, P);
+    }
+    template <bool UNI = false>
+    static __device__ __forceinline__ void inv(T &x, T &y, T w, T, const ModParams<T> &P) {
+        const T d = sub_full(x, y, P);
+        x = add_full(x, y, P);
+        y = mulc<UNI>(d, w, P);
+    }
+    static __device__ __forceinline__ void inv_norm(T &x, T &y, const ModParams<T> &P) {
+        const T d = sub_full(x, y, P), s = add_full(x, y, P);
+        x = mulc<true>(s, P.pm_n_inv, P);
+        y = mulc<true>(d, P.pm_last_w, P);
+    }
+    static __device__ __forceinline__ T finish_fwd(T v, const ModParams<T> &P) { return canon(v, P); }
+    static __device__ __forceinline__ T finish_inv(T v, const ModParams<T> &P) { return canon(v, P); }
+};
 
 // ---------------------------------------------------------------------------------------------
 // pointwise kernels' arithmetic (src/prime64.rs:534-584,690-699; src/prime32.rs:383-408,...)
@@ -401,7 +510,9 @@ template <class T> __device__ __forceinline__ T mul_normalize(T a, T b, const Mo
 // a*b in the range the inverse butterflies of class CLS accept, WITHOUT the 1/N factor (Bfly::inv_norm applies it):
 // LAZY [0, 2p); STRICT canonical; GENERIC a b / R canonical (inv_norm's constants carry the R^2).
 template <class T, int CLS> __device__ __forceinline__ T mul_for_inv(T a, T b, const ModParams<T> &P) {
-    if constexpr (is_fp_class(CLS)) {
+    if constexpr (CLS == CLS_PM64) {
+        return Bfly<T, CLS>::template mulc<false>(a, b, P);  // a: any representative, b: canonical word from memory
+    } else if constexpr (is_fp_class(CLS)) {
         // a: the forward transform's lazy double (|a| < 2^53), b: a canonical word from memory; result |.| <= 0.875 p
         const double p = Fp::d(P.fp_p), pinv = Fp::d(P.fp_pinv);
         return Fp::u(Fp::mul_data(Fp::reduce(Fp::d(a), p, pinv), Fp::from_word(b), p, pinv));
@@ -436,7 +547,9 @@ template <class T> __device__ __forceinline__ T mul_acc(T acc, T a, T b, const M
 // acc + a * b in the accumulator form of class CLS (the fused mul_accumulate chains): the integer classes keep
 // canonical accumulators; the double classes add the product (|.| <= 0.875 p, `a` already range-reduced) to a lazy double.
 template <class T, int CLS> __device__ __forceinline__ T mul_acc_cls(T acc, T a, T b, const ModParams<T> &P) {
-    if constexpr (is_fp_class(CLS)) {
+    if constexpr (CLS == CLS_PM64) {
+        return Bfly<T, CLS>::add_c(acc, Bfly<T, CLS>::template mulc<false>(a, b, P), P);
+    } else if constexpr (is_fp_class(CLS)) {
         const double p = Fp::d(P.fp_p), pinv = Fp::d(P.fp_pinv);
         return Fp::u(__dadd_rn(Fp::d(acc), Fp::mul_data(Fp::d(a), Fp::from_word(b), p, pinv)));
     } else {

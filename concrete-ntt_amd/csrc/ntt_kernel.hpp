@@ -660,7 +660,7 @@ struct MulWp {
                 F::wsync();
             }
             // NTT-domain values in layout RMM: canonical, or (CLS_FP) the lazy doubles mul_for_inv takes
-            F::template pass<0, false, true, !Bfly<T, CLS>::IS_FP>(r, lds, tid, twf, imgf, P);
+            F::template pass<0, false, true, !Bfly<T, CLS>::FUSED_LAZY>(r, lds, tid, twf, imgf, P);
             {
                 // clamped polynomial index for the reads of a ragged tail
                 const uint32_t lastc = nsub - 1u - tile * PPB;
@@ -790,7 +790,7 @@ struct ExtWp {
                     F::wsync();
                 }
                 // NTT-domain values in layout RMM: canonical, or (CLS_FP) range-reduced doubles
-                F::template pass<0, false, true, !Bfly<T, CLS>::IS_FP>(r, lds, tid, twf, imgf, P);
+                F::template pass<0, false, true, !Bfly<T, CLS>::FUSED_LAZY>(r, lds, tid, twf, imgf, P);
                 if constexpr (Bfly<T, CLS>::IS_FP) {
 #pragma unroll
                     for (int e = 0; e < E; ++e) r[e] = Bfly<T, CLS>::reduce(r[e], P);

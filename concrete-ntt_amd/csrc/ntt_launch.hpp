@@ -23,8 +23,9 @@ template <class T, bool INV>
 hipError_t launch_ntt(int logn, int cls, T *data, const TwPair<T> *tw, const ModParams<T> &P, uint32_t nsub,
                       uint32_t depth, hipStream_t stream);
 
-// CLS_FP / CLS_FP51 (64-bit words, p < 2^50 / 2^51) instances of the two launches above, each class in a translation
-// unit of its own (ntt_inst_u64_fp.hip, ntt_inst_u64_fp51.hip).  `tw` / `twf` / `twi` are the plan's (c, c/p) double tables.
+// The 64-bit-only classes CLS_FP / CLS_FP51 (p < 2^50 / 2^51) and CLS_PM64 (p = 2^64 - c): instances of the two launches
+// above, each class in a translation unit of its own (ntt_inst_u64_fp.hip, ntt_inst_u64_fp51.hip, ntt_inst_u64_pm.hip).
+// `tw` / `twf` / `twi` are the plan's tables for that class ((c, c/p) doubles; plain residues).
 template <int CLS>
 hipError_t launch_ntt_fp(int logn, bool inv, uint64_t *data, const TwPair<uint64_t> *tw, const ModParams<uint64_t> &P,
                          uint32_t nsub, hipStream_t stream);

@@ -47,7 +47,9 @@ static hipError_t launch_one(T *data, const TwPair<T> *tw, const ModParams<T> &P
         if (grid > ntiles) grid = ntiles;
         hipLaunchKernelGGL((ntt_kernel_wp<T, LOGN, INV, CLS, WP_BLOCK, BPC>), dim3(grid), dim3(WP_BLOCK), 0, stream, data,
                            tw, P, nsub);
-    } else if constexpr (wpg_eligible<K>() && !SUB) {
+    } else if constexpr (wpg_eligible<K>() && !SUB && !(CLS == CLS_PM64 && INV && LOGN == 14)) {
+        // (the one excluded instance does not fit the 128 VGPRs of a 1024-thread workgroup without spilling, and a
+        // spilled register must never meet the asynchronous prefetch: it runs on ntt_kernel below)
         constexpr int WPB = K::TPP;
         using W = NttWp<T, LOGN, INV, CLS, WPB>;
         constexpr size_t LDS_BYTES = ((size_t)W::PPB << LOGN) * sizeof(T);

@@ -75,6 +75,8 @@ def test_plans_match_oracle(oracle, bits, n, p):
     expect_cls = 0 if p < (1 << (bits - 2)) else (1 if p < (1 << (bits - 1)) else 2)
     if bits == 64 and p < (1 << 51) and n <= 16384:
         expect_cls = 3 if p < (1 << 50) else 4   # double-precision FMA butterflies (csrc/ntt_arith.hpp, CLS_FP / CLS_FP51)
+    if bits == 64 and p >= (1 << 63) and (1 << 64) - p < (1 << 32) and n <= 16384:
+        expect_cls = 5   # p = 2^64 - c, c < 2^32 (CLS_PM64)
     assert info.arith_class == expect_cls
 
 
@@ -140,7 +142,7 @@ def test_async_load_kernels_do_not_spill(tmp_path):
     objdir = os.path.join(ROOT, "concrete-ntt_amd", "csrc", "_obj")
     checked = 0
     for unit in ("ntt_inst_u64_fwd", "ntt_inst_u64_inv", "ntt_inst_u32_fwd", "ntt_inst_u32_inv", "ntt_inst_u64_mul",
-                 "ntt_inst_u32_mul"):
+                 "ntt_inst_u32_mul", "ntt_inst_u64_fp", "ntt_inst_u64_fp51", "ntt_inst_u64_pm"):
         obj = os.path.join(objdir, unit + ".o")
         if not os.path.exists(obj):
             pytest.skip("objects not built in-tree (run __graft_entry__.build())")

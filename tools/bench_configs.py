@@ -179,6 +179,10 @@ if __name__ == "__main__":
         P51 = 2251799813554177
         for n, b in ((1024, 65536), (4096, 16384), (16384, 4096)):
             prime_case(prime64, 64, n, P51, b, "prime64 51-bit")
+    if "pm64" in which:   # CLS_PM64: Solinas and the largest prime below 2^64 (benches/ntt.rs:116-117)
+        for pp, tag in ((18446744069414584321, "Solinas"), (18446744073707716609, "64-bit")):
+            for n, b in ((1024, 65536), (4096, 16384)):
+                prime_case(prime64, 64, n, pp, b, "prime64 " + tag)
     if "p64n2048" in which:
         prime_case(prime64, 64, 2048, P62, 32768, "prime64")
     if "c3" in which:
