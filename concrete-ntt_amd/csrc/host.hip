@@ -633,9 +633,15 @@ static const NativeKindInfo NATIVE_KINDS[10] = {
     {2, 8, 1, 1, 2, {0, 1, 0, 0, 0}, {-1, -1, -1, -1, -1}},   // native_binary64::Plan52    src/native_binary64.rs:230-260
 };
 
+// One grow-only scratch area per (plan, device) for the composed native pipeline.  Calls from several threads or on
+// several streams share it safely: the plan's mutex is held while a call enqueues its launches, and a call on another
+// stream first waits for the event the previous user recorded (no wait, no record while a stream is being captured
+// into a hipGraph: a graph replays against the buffer it captured, as cntt_native_reserve documents).
 struct Workspace {
     void *base = nullptr;
     size_t bytes = 0;
+    hipEvent_t last = nullptr;
+    hipStream_t last_stream = nullptr;
 };
 struct NativeCache {
     std::mutex mu;
@@ -646,6 +652,7 @@ struct NativeCache {
             if (hipGetDevice(&cur) != hipSuccess) continue;
             (void)hipSetDevice(kv.first);
             (void)hipFree(kv.second.base);
+            if (kv.second.last) (void)hipEventDestroy(kv.second.last);
             (void)hipSetDevice(cur);
         }
     }
@@ -906,11 +913,11 @@ extern "C" int cntt_native_inv_batch(const cntt_native_t *pl, void *value, void 
     return native_op(pl, 2, value, res, batch, where, (hipStream_t)st);
 }
 
-static int native_workspace(const cntt_native *pl, size_t batch, void **base) {
+// caller holds pl->cache->mu
+static int native_workspace(const cntt_native *pl, size_t batch, Workspace **out) {
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     const size_t need = 2 * (size_t)pl->info.nprimes * batch * pl->n * pl->rbytes();
-    std::lock_guard<std::mutex> lk(pl->cache->mu);
     Workspace &w = pl->cache->ws[dev];
     if (w.bytes < need) {
         if (w.base) {
@@ -925,13 +932,14 @@ static int native_workspace(const cntt_native *pl, size_t batch, void **base) {
         }
         w.bytes = need;
     }
-    *base = w.base;
+    *out = &w;
     return CNTT_OK;
 }
 extern "C" int cntt_native_reserve(const cntt_native_t *pl, size_t batch) {
     if (!pl) return fail(CNTT_EINVAL, "plan is NULL");
-    void *b = nullptr;
-    return native_workspace(pl, batch, &b);
+    std::lock_guard<std::mutex> lk(pl->cache->mu);
+    Workspace *w = nullptr;
+    return native_workspace(pl, batch, &w);
 }
 
 // negacyclic_polymul on device memory: src/native64.rs:1042-1069 batched
@@ -973,8 +981,25 @@ static int native_polymul_device(const cntt_native *pl, void *prod, const void *
         if (e != hipErrorNotSupported) return fail(CNTT_EDEVICE, "fused polymul launch failed: %s", hipGetErrorString(e));
         (void)hipGetLastError();
     }
-    void *base = nullptr;
-    if (int rc = native_workspace(pl, batch, &base)) return rc;
+    std::lock_guard<std::mutex> lk(pl->cache->mu);  // held while this call's launches are enqueued
+    Workspace *ws = nullptr;
+    if (int rc = native_workspace(pl, batch, &ws)) return rc;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(st, &cap);
+    const bool capturing = cap != hipStreamCaptureStatusNone;
+    if (!capturing && ws->last && ws->last_stream != st) HIP_TRY(hipStreamWaitEvent(st, ws->last, 0));
+    struct Release {  // records "done with the workspace" on every exit path
+        Workspace *w;
+        hipStream_t st;
+        bool on;
+        ~Release() {
+            if (!on) return;
+            if (!w->last && hipEventCreateWithFlags(&w->last, hipEventDisableTiming) != hipSuccess) w->last = nullptr;
+            if (w->last) (void)hipEventRecord(w->last, st);
+            w->last_stream = st;
+        }
+    } release{ws, st, !capturing};
+    void *base = ws->base;
     const int k = pl->info.nprimes;
     const size_t count = batch * pl->n, rb = count * pl->rbytes();
     void *L[10], *R[10];

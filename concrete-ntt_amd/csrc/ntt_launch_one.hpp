@@ -47,9 +47,13 @@ static hipError_t launch_one(T *data, const TwPair<T> *tw, const ModParams<T> &P
         if (grid > ntiles) grid = ntiles;
         hipLaunchKernelGGL((ntt_kernel_wp<T, LOGN, INV, CLS, WP_BLOCK, BPC>), dim3(grid), dim3(WP_BLOCK), 0, stream, data,
                            tw, P, nsub);
-    } else if constexpr (wpg_eligible<K>() && !SUB && !(CLS == CLS_PM64 && INV && LOGN == 14)) {
-        // (the one excluded instance does not fit the 128 VGPRs of a 1024-thread workgroup without spilling, and a
-        // spilled register must never meet the asynchronous prefetch: it runs on ntt_kernel below)
+    } else if constexpr (wpg_eligible<K>() && !SUB && sizeof(T) == 8 && CLS != CLS_GENERIC &&
+                         !(CLS == CLS_PM64 && INV && LOGN == 14)) {
+        // Measured (profiles/r02_bench_grid_table.txt vs r01_v6): the persistent walk pays for the 64-bit classes whose
+        // butterflies are cheap enough to expose memory latency (CLS_FP +30..45 %, lazy / strict forward +5..10 %); the
+        // 32-bit transforms and the Montgomery class ran 5..20 % slower on it and stay on ntt_kernel.  One CLS_PM64
+        // instance does not fit the 128 VGPRs of a 1024-thread workgroup without spilling (a spilled register must
+        // never meet the asynchronous prefetch) and stays there too.
         constexpr int WPB = K::TPP;
         using W = NttWp<T, LOGN, INV, CLS, WPB>;
         constexpr size_t LDS_BYTES = ((size_t)W::PPB << LOGN) * sizeof(T);
