@@ -236,8 +236,15 @@ struct NttKernel {
                 r[j] = (T)v[j / MAXV][0] | ((T)v[j / MAXV][1] << 32);
                 r[j + 1] = (T)v[j / MAXV][2] | ((T)v[j / MAXV][3] << 32);
             } else {
+                // An explicit move AFTER the wait: a plain copy lets hipcc satisfy the wait statement's tied operand by
+                // copying the (not yet landed) destination register into the loop-carried register BEFORE the
+                // s_waitcnt (seen in every u32 instance; tests/test_async_load_guard.py now checks the code objects).
 #pragma unroll
-                for (int i = 0; i < 4; ++i) r[j + i] = (T)v[j / MAXV][i];
+                for (int i = 0; i < 4; ++i) {
+                    uint32_t x;
+                    asm("v_mov_b32 %0, %1" : "=v"(x) : "v"(v[j / MAXV][i]));
+                    r[j + i] = (T)x;
+                }
             }
         }
     }

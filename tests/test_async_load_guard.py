@@ -1,0 +1,118 @@
+"""Guard for the software-pipelined kernels' inline-asm prefetch (csrc/ntt_kernel.hpp gather_async / wait_async): the
+compiler believes the destination registers of those global_load_dwordx4 are valid at once, while the data lands later.
+Nothing may read or write such a register between the load and the s_waitcnt that retires it.  This test replays the
+vmcnt queue along every control-flow path of the disassembly of every persistent kernel and fails if any instruction touches a destination register of a vector-memory load still in flight --
+whatever hipcc's register allocator does in a future ROCm, a violation shows up here and not as silent corruption.
+Built with ROCm 7.2 (hipcc / AMD clang 22); pinned in INTEGRATION.md."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LLVM = "/opt/rocm/lib/llvm/bin"
+OBJ = os.path.join(ROOT, "concrete-ntt_amd", "csrc", "_obj")
+UNITS = ("ntt_inst_u64_fwd", "ntt_inst_u64_inv", "ntt_inst_u64_mul", "ntt_inst_u32_fwd", "ntt_inst_u32_inv",
+         "ntt_inst_u32_mul", "ntt_inst_u64_fp", "ntt_inst_u64_fp51", "ntt_inst_u64_pm")
+VMEM = ("global_load", "global_store", "buffer_load", "buffer_store", "scratch_load", "scratch_store", "global_atomic",
+        "flat_load", "flat_store")
+
+
+def regs_of(tok):
+    m = re.match(r"v\[(\d+):(\d+)\]$", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.match(r"v(\d+)$", tok)
+    return {int(m.group(1))} if m else set()
+
+
+def operands(line):
+    rest = line.split(None, 1)[1] if " " in line else ""
+    toks, cur = [], ""
+    for part in rest.split(","):
+        cur = cur + "," + part if cur else part
+        if cur.count("[") == cur.count("]"):
+            toks.append(cur.strip().split()[0] if cur.strip() else "")
+            cur = ""
+    return toks
+
+
+def check_kernel(name, insts):
+    """insts: [(address, text)] in layout order.  From every vector-memory load, walk forward until the s_waitcnt that
+    retires it (vmcnt(N) leaves only the N youngest operations in flight) and require that nothing on the way touches
+    its destination registers.  Two walks per load cover both loop layouts hipcc produces for the persistent kernels:
+    conditional branches never taken, and backward conditional branches taken when they land on a wait (the prefetch's
+    wait opens the loop latch, which may precede the loop body; the other backward branch of that layout re-tests the
+    condition that guarded the prefetch and leaves the loop); unconditional branches are followed in both."""
+    index = {a: k for k, (a, _) in enumerate(insts)}
+    parsed = []
+    for addr, ln in insts:
+        op = ln.split()[0]
+        toks = operands(ln)
+        touched = set()
+        for t in toks:
+            touched |= regs_of(t)
+        target = None
+        if op == "s_branch" or op.startswith("s_cbranch"):
+            off = int(ln.split()[1])
+            off = off - 65536 if off >= 32768 else off
+            target = index[addr + 4 + 4 * off]
+        m = re.search(r"vmcnt\((\d+)\)", ln) if op == "s_waitcnt" else None
+        parsed.append((op, touched, target, int(m.group(1)) if m else None, regs_of(toks[0]) if toks else set()))
+    loads = 0
+    for k0, (op0, _, _, _, dst) in enumerate(parsed):
+        if not (op0.startswith(VMEM) and "load" in op0 and not op0.startswith("scratch")):
+            continue
+        loads += 1
+        for take_backward in (False, True):
+            k, younger, steps = k0 + 1, 0, 0
+            while k < len(parsed) and steps < 40000:
+                steps += 1
+                op, touched, target, keep, _ = parsed[k]
+                if k == k0 or op == "s_endpgm":
+                    break
+                if keep is not None:
+                    if younger >= keep:
+                        break           # retired
+                elif target is not None:
+                    latch = any(parsed[t][3] is not None for t in range(target, min(target + 2, len(parsed))))
+                    if op == "s_branch" or (take_backward and target <= k and latch):
+                        k = target
+                        continue
+                else:
+                    if op.startswith(VMEM) and "load" in op:
+                        touched = touched - parsed[k][4]   # a younger load may overwrite it: loads return in order
+                    assert not (touched & dst), "%s: `%s` touches v%s of `%s` still in flight" % (
+                        name, insts[k][1], sorted(touched & dst), insts[k0][1])
+                    if op.startswith(VMEM):
+                        younger += 1
+                k += 1
+    return loads
+
+
+def test_no_instruction_touches_a_load_in_flight(tmp_path):
+    if not os.path.exists(os.path.join(LLVM, "llvm-objdump")):
+        pytest.skip("ROCm LLVM tools not present")
+    checked = 0
+    for unit in UNITS:
+        obj = os.path.join(OBJ, unit + ".o")
+        if not os.path.exists(obj):
+            pytest.skip("objects not built in-tree (run __graft_entry__.build())")
+        fat, co = str(tmp_path / (unit + ".fat")), str(tmp_path / (unit + ".co"))
+        subprocess.run([os.path.join(LLVM, "llvm-objcopy"), "-O", "binary", "--only-section=.hip_fatbin", obj, fat], check=True)
+        subprocess.run([os.path.join(LLVM, "clang-offload-bundler"), "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                        "--input=" + fat, "--output=" + co, "--unbundle"], check=True)
+        dis = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", co], check=True, capture_output=True, text=True).stdout
+        name, body = None, []
+        for ln in dis.split("\n") + ["0 <end>:"]:
+            m = re.match(r"^[0-9a-f]+ <(\S+)>:", ln)
+            if m:
+                if name and "_wp" in name and body:
+                    assert check_kernel(name, body) > 0
+                    checked += 1
+                name, body = m.group(1), []
+            elif ln.startswith("\t") and "//" in ln:
+                text, _, tail = ln.partition("//")
+                body.append((int(tail.split(":")[0].strip(), 16), text.strip()))
+    assert checked > 80

@@ -46,7 +46,7 @@ def census(T, cls, inv):
         text = open(out).read()
     counts = []
     for nb in (4, 12):
-        m = re.search(r"^_ZN?\w*1kI\w*Li%dEEvPT_\w*:\n(.*?)s_endpgm" % nb, text, re.S | re.M)
+        m = re.search(r"^_Z1kI\w*Li%dEEvPT_\w*:[^\n]*\n(.*?)s_endpgm" % nb, text, re.S | re.M)
         body = m.group(1)
         c = collections.Counter()
         for ln in body.split("\n"):
