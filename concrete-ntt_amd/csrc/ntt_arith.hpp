@@ -272,6 +272,60 @@ template <class T, int CLS> struct Bfly {
 };
 
 // ---------------------------------------------------------------------------------------------
+// 32-bit lazy class in 64-bit "boxes" (registers only): a coefficient is the LOW word of a 64-bit VGPR pair whose high
+// word is don't-care.  v_mad_u64_u32 takes such a pair as its addend, so the forward butterfly's
+//     x' = x + y w + q (-p)     (mod 2^32, q = hi32(y ws))
+// is two multiply-adds instead of two v_mul_lo_u32, a subtraction and an addition: 7 instructions per butterfly instead
+// of 8.5 (profiles/r02_butterfly_census.txt).  Every native / native_binary Plan32 product is 9..30 such transforms.
+// The boxes exist inside a pass's register stages only; LDS and HBM hold plain 32-bit words.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t box32(uint32_t v) {
+    uint32_t junk;
+    junk = __builtin_nondeterministic_value(junk);  // no instruction: the high word is whatever the register holds
+    return ((uint64_t)junk << 32) | v;
+}
+template <bool UNI> __device__ __forceinline__ uint64_t mad_box(uint32_t a, uint32_t b, uint64_t c) {  // low word: a b + c
+    uint64_t r;
+    if constexpr (UNI) asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c) : "vcc");
+    else asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c) : "vcc");
+    return r;
+}
+template <bool UNI> __device__ __forceinline__ uint64_t mul_box(uint32_t a, uint32_t b) {  // low word: a b
+    uint64_t r;
+    if constexpr (UNI) asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(r) : "v"(a), "s"(b) : "vcc");
+    else asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b) : "vcc");
+    return r;
+}
+template <int CLS> struct BoxOps {
+    template <class T> struct USE { static constexpr bool value = sizeof(T) == 4 && CLS == CLS_LAZY; };
+    using P32 = ModParams<uint32_t>;
+    // (x, y) <- (x + w y, x - w y), values in [0, 4p)
+    template <bool UNI> static __device__ __forceinline__ void fwd(uint64_t &X, uint64_t &Y, uint32_t w, uint32_t ws, const P32 &P) {
+        const uint32_t x = umin<uint32_t>((uint32_t)X, (uint32_t)X - P.two_p);
+        const uint32_t y = (uint32_t)Y;
+        const uint32_t q = __umulhi(y, ws);
+        const uint64_t a = mad_box<UNI>(y, w, box32(x));
+        X = mad_box<true>(q, P.neg_p, a);                       // x + t, t = y w - q p in [0, 2p)
+        Y = box32((x << 1) + P.two_p - (uint32_t)X);            // x - t + 2p
+    }
+    // (x, y) <- (x + y, (x - y) w), values in [0, 2p)
+    template <bool UNI> static __device__ __forceinline__ void inv(uint64_t &X, uint64_t &Y, uint32_t w, uint32_t ws, const P32 &P) {
+        const uint32_t x = (uint32_t)X, y = (uint32_t)Y;
+        const uint32_t d = (x + P.two_p) - y;
+        const uint32_t s = x + y;
+        X = box32(umin<uint32_t>(s, s - P.two_p));
+        const uint32_t q = __umulhi(d, ws);
+        Y = mad_box<true>(q, P.neg_p, mul_box<UNI>(d, w));
+    }
+    static __device__ __forceinline__ void inv_norm(uint64_t &X, uint64_t &Y, const P32 &P) {
+        inv<true>(X, Y, P.last_w, P.last_w_shoup, P);
+        const uint32_t x = (uint32_t)X;
+        const uint32_t q = __umulhi(x, P.n_inv_shoup);
+        X = mad_box<true>(q, P.neg_p, mul_box<true>(x, P.n_inv));   // [0, 2p)
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
 // CLS_FP / CLS_FP51: residues as exact integers in doubles (64-bit words, p < 2^50 / p < 2^51)
 //
 // A register holds the bit pattern of a double v, an exact integer with v = residue (mod p) and |v| < 2^53.

@@ -11,6 +11,8 @@
 // N <= 64 * 2^LOGE it lives inside ONE 64-lane wavefront and the exchanges need no workgroup
 // barrier (LDS operations of one wave execute in order); larger N use __syncthreads().
 #pragma once
+#include <type_traits>
+
 #include "ntt_arith.hpp"
 
 namespace cntt {
@@ -323,8 +325,10 @@ struct NttKernel {
 
     // NORM (inverse only): the stage on the top index bit -- the last one, one twiddle inv_twid[1] for all of its
     // butterflies -- also applies the 1/N normalisation (Bfly::inv_norm).
-    template <int K, int GI, bool IMG = false, bool NORM = false, int TWC = 0>
-    static __device__ __forceinline__ void stage(T (&r)[E], uint32_t ebase, uint32_t qpre, uint32_t depth,
+    // R: the register form of a coefficient -- T itself, or (32-bit lazy class) a 64-bit "box" whose low word is the
+    // value and whose high word is don't-care, the form in which x + y w + q (-p) is two v_mad_u64_u32 (BoxOps).
+    template <int K, int GI, bool IMG = false, bool NORM = false, int TWC = 0, class R = T>
+    static __device__ __forceinline__ void stage(R (&r)[E], uint32_t ebase, uint32_t qpre, uint32_t depth,
                                                  const TwPair<T> *__restrict__ tw, const ModParams<T> &P,
                                                  uint32_t tid = 0, const TwPair<T> *img = nullptr) {
         constexpr uint32_t RM = S::RMASK[K], GM = S::GMASK[K], CM = FULL & ~RM;
@@ -340,7 +344,8 @@ struct NttKernel {
 #pragma unroll
             for (int j = 0; j < E; ++j) {
                 if ((j >> k) & 1) continue;
-                Bfly<T, CLS>::inv_norm(r[j], r[j | (1 << k)], P);
+                if constexpr (std::is_same<R, T>::value) Bfly<T, CLS>::inv_norm(r[j], r[j | (1 << k)], P);
+                else BoxOps<CLS>::inv_norm(r[j], r[j | (1 << k)], P);
             }
             return;
         }
@@ -370,7 +375,10 @@ struct NttKernel {
                 if (h < h0 || h >= h0 + CH) continue;
                 // twiddles that do not depend on the thread come from scalar loads and stay in SGPRs (never for the
                 // sub-block kernels: their table prefix depends on the polynomial a thread works on)
-                if constexpr (INV)
+                if constexpr (!std::is_same<R, T>::value) {
+                    if constexpr (INV) BoxOps<CLS>::template inv<UNI>(r[j], r[j | (1 << k)], w[h - h0].w, w[h - h0].ws, P);
+                    else BoxOps<CLS>::template fwd<UNI>(r[j], r[j | (1 << k)], w[h - h0].w, w[h - h0].ws, P);
+                } else if constexpr (INV)
                     Bfly<T, CLS>::template inv<UNI>(r[j], r[j | (1 << k)], w[h - h0].w, w[h - h0].ws, P);
                 else
                     Bfly<T, CLS>::template fwd<UNI>(r[j], r[j | (1 << k)], w[h - h0].w, w[h - h0].ws, P);
@@ -395,13 +403,29 @@ struct NttKernel {
         }
     }
 
+    template <int K, int GI, bool IMG, bool NORM, int TWC, class R>
+    static __device__ __forceinline__ void stages_r(R (&r)[E], uint32_t ebase, uint32_t qpre, uint32_t depth,
+                                                    const TwPair<T> *__restrict__ tw, const ModParams<T> &P, uint32_t tid,
+                                                    const TwPair<T> *img) {
+        if constexpr (GI < cpop(S::GMASK[K])) {
+            stage<K, GI, IMG, NORM, TWC, R>(r, ebase, qpre, depth, tw, P, tid, img);
+            stages_r<K, GI + 1, IMG, NORM, TWC, R>(r, ebase, qpre, depth, tw, P, tid, img);
+        }
+    }
+    // all register-resident stages of pass K
     template <int K, int GI = 0, bool IMG = false, bool NORM = false, int TWC = 0>
     static __device__ __forceinline__ void stages(T (&r)[E], uint32_t ebase, uint32_t qpre, uint32_t depth,
                                                   const TwPair<T> *__restrict__ tw, const ModParams<T> &P,
                                                   uint32_t tid = 0, const TwPair<T> *img = nullptr) {
-        if constexpr (GI < cpop(S::GMASK[K])) {
-            stage<K, GI, IMG, NORM, TWC>(r, ebase, qpre, depth, tw, P, tid, img);
-            stages<K, GI + 1, IMG, NORM, TWC>(r, ebase, qpre, depth, tw, P, tid, img);
+        if constexpr (BoxOps<CLS>::template USE<T>::value) {
+            uint64_t c[E];
+#pragma unroll
+            for (int j = 0; j < E; ++j) c[j] = box32((uint32_t)r[j]);
+            stages_r<K, GI, IMG, NORM, TWC, uint64_t>(c, ebase, qpre, depth, tw, P, tid, img);
+#pragma unroll
+            for (int j = 0; j < E; ++j) r[j] = (T)(uint32_t)c[j];
+        } else {
+            stages_r<K, GI, IMG, NORM, TWC, T>(r, ebase, qpre, depth, tw, P, tid, img);
         }
     }
 
