@@ -259,6 +259,8 @@ template <class T, int CLS> struct Bfly {
     // a word as loaded from memory -> the class's register form (identity for the integer classes)
     static __device__ __forceinline__ T load_fix(T v) { return v; }
     static __device__ __forceinline__ T reduce(T v, const ModParams<T> &) { return v; }
+    // an accumulator of the fused chains -> what the inverse transform's first stage accepts
+    static __device__ __forceinline__ T pre_inverse(T v, const ModParams<T> &) { return v; }
     // bring a value left by the last stage into [0, p)
     static __device__ __forceinline__ T finish_fwd(T v, const ModParams<T> &P) {
         if constexpr (CLS == CLS_LAZY) return csub<T>(csub_two_p<T>(v, P.two_p, P.neg_two_p), P.p);
@@ -394,6 +396,7 @@ template <class T, int HEAD> struct BflyFp {
     static __device__ __forceinline__ T reduce(T v, const ModParams<T> &P) {
         return Fp::u(Fp::reduce(Fp::d(v), Fp::d(P.fp_p), Fp::d(P.fp_pinv)));
     }
+    static __device__ __forceinline__ T pre_inverse(T v, const ModParams<T> &P) { return reduce(v, P); }  // |v| <= p
     template <bool UNI = false>
     static __device__ __forceinline__ void fwd(T &x, T &y, T w, T ws, const ModParams<T> &P) {
         const double t = Fp::mul_const(Fp::d(y), Fp::d(w), Fp::d(ws), Fp::d(P.fp_p));
@@ -430,8 +433,9 @@ __host__ __device__ constexpr bool is_fp_class(int cls) { return cls == CLS_FP |
 //             = L + H0 c + (H1 c) 2^32       three 32-bit limbs and a top word  top = hi32(H1 c) + carries <= c + 1
 //             = (limbs) + top c              one more multiply-add, at most one further carry (+ c)
 //             w < p bounds H <= p - 2, which keeps `top` inside 32 bits even for c = 2^32 - 1 (then H1 <= 2^32 - 2).
-//   sum / difference with a canonical second operand: one wrap at most, corrected by +-c (2^64 = c); with two
-//             arbitrary representatives a second wrap is possible and corrected the same way.
+//   sum / difference with a canonical second operand: one wrap at most, corrected by +-c (2^64 = c).  The forward
+//             transform leaves any representative (its x role only ever meets canonical products); the inverse keeps
+//             everything canonical (sums of two canonical values: one conditional -p).
 // The reference computes exact `%` products here (src/prime64/generic_solinas.rs:42-128): same residues.
 // One inline-asm block (fixed scratch v[2:7], two wait states behind every VALU-written SGPR, see shoup_core).
 // ---------------------------------------------------------------------------------------------
@@ -490,36 +494,33 @@ template <class T> struct Bfly<T, CLS_PM64> {
         const T d = x - t;
         return d - (x < t ? (T)P.pm_c : (T)0);
     }
-    // x + y, x - y for any two representatives
-    static __device__ __forceinline__ T add_full(T x, T y, const ModParams<T> &P) {
-        const T s = x + y;
-        const T s2 = s + (s < x ? (T)P.pm_c : (T)0);
-        return s2 + (s2 < s ? (T)P.pm_c : (T)0);
-    }
-    static __device__ __forceinline__ T sub_full(T x, T y, const ModParams<T> &P) {
-        const T d = x - y;
-        const T d2 = d - (x < y ? (T)P.pm_c : (T)0);
-        return d2 - (d2 > d ? (T)P.pm_c : (T)0);
-    }
     template <bool UNI = false>
     static __device__ __forceinline__ void fwd(T &x, T &y, T w, T, const ModParams<T> &P) {
         const T t = mulc<UNI>(y, w, P);
         y = sub_c(x, t, P);
         x = add_c(x, t, P);
     }
+    // The inverse keeps every value CANONICAL (its inputs are: memory words, products, or pre_inverse()d accumulators):
+    // a canonical sum is one add, two compares and a conditional +c; the difference wraps at most once.
+    static __device__ __forceinline__ T add_canon(T x, T y, const ModParams<T> &P) {
+        const T s = x + y;
+        const bool k = (s < x) | (s >= P.p);           // passed 2^64, or landed in [p, 2^64)
+        return s + (k ? (T)P.pm_c : (T)0);             // - p
+    }
     template <bool UNI = false>
     static __device__ __forceinline__ void inv(T &x, T &y, T w, T, const ModParams<T> &P) {
-        const T d = sub_full(x, y, P);
-        x = add_full(x, y, P);
+        const T d = sub_c(x, y, P);
+        x = add_canon(x, y, P);
         y = mulc<UNI>(d, w, P);
     }
     static __device__ __forceinline__ void inv_norm(T &x, T &y, const ModParams<T> &P) {
-        const T d = sub_full(x, y, P), s = add_full(x, y, P);
+        const T d = sub_c(x, y, P), s = add_c(x, y, P);   // both go straight into products: any representative will do
         x = mulc<true>(s, P.pm_n_inv, P);
         y = mulc<true>(d, P.pm_last_w, P);
     }
+    static __device__ __forceinline__ T pre_inverse(T v, const ModParams<T> &P) { return canon(v, P); }
     static __device__ __forceinline__ T finish_fwd(T v, const ModParams<T> &P) { return canon(v, P); }
-    static __device__ __forceinline__ T finish_inv(T v, const ModParams<T> &P) { return canon(v, P); }
+    static __device__ __forceinline__ T finish_inv(T v, const ModParams<T> &) { return v; }  // canonical already
 };
 
 // ---------------------------------------------------------------------------------------------

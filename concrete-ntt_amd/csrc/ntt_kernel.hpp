@@ -841,10 +841,8 @@ struct ExtWp {
             }
             static_for<0, NOUT>([&](auto o) {
                 T(&a)[E] = acc[o.value];
-                if constexpr (Bfly<T, CLS>::IS_FP) {  // the inverse expects |inputs| <= p
 #pragma unroll
-                    for (int e = 0; e < E; ++e) a[e] = Bfly<T, CLS>::reduce(a[e], P);
-                }
+                for (int e = 0; e < E; ++e) a[e] = Bfly<T, CLS>::pre_inverse(a[e], P);  // lazy accumulator -> inverse input
                 I::template pass<0>(a, lds, tid, twi, imgi, P);  // canonical coefficients, layout RML
                 if constexpr (RML != IO_RM) {
                     F::wsync();
