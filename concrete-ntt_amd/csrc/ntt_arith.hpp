@@ -6,7 +6,8 @@
 // Three arithmetic classes, chosen per plan at creation from the modulus:
 //   CLS_LAZY    p < 2^(B-2): Harvey lazy butterflies, values in [0,4p) (fwd) / [0,2p) (inv), as
 //               src/prime64/less_than_62bit.rs:117-154,271-310 and src/prime32/less_than_30bit.rs
-//   CLS_STRICT  p < 2^(B-1): values in [0,2p), as src/prime64/less_than_63bit.rs:117-154,214-232
+//   CLS_STRICT  p < 2^(B-1): values in [0,2p), as src/prime64/less_than_63bit.rs:117-154,214-232 (the sums that may
+//               pass 2^B are corrected with their carry)
 //   CLS_GENERIC any p (used for p >= 2^(B-1), incl. Solinas): canonical values, Montgomery
 //               products against twiddles stored in Montgomery form.  The reference does exact
 //               `%`-products there (src/prime64/generic_solinas.rs:42-128): same values.
@@ -213,10 +214,13 @@ template <class T, int CLS> struct Bfly {
                 x = x + t;
             }
         } else if constexpr (CLS == CLS_STRICT) {
-            x = csub<T>(x, P.p);
-            const T t = csub<T>(shoup_mul<T, UNI>(y, w, ws, P.neg_p), P.p);
-            y = x - t + P.p;
-            x = x + t;
+            // x, t in [0, 2p), 2p < 2^B <= 4p: the sum may pass 2^B -- one carry-aware conditional subtraction of 2p on
+            // each output instead of bringing x and t below p first
+            const T t = shoup_mul<T, UNI>(y, w, ws, P.neg_p);
+            const T s = x + t;
+            const T d = x - t;
+            y = d + (x < t ? P.two_p : (T)0);
+            x = s + (((s < x) | (s >= P.two_p)) ? P.neg_two_p : (T)0);
         } else {
             const T t = mont_mul(y, w, P.p, P.pinv_neg);
             const T x0 = x;
@@ -232,9 +236,10 @@ template <class T, int CLS> struct Bfly {
             x = csub_two_p<T>(x + y, P.two_p, P.neg_two_p);
             y = shoup_mul<T, UNI>(d, w, ws, P.neg_p);
         } else if constexpr (CLS == CLS_STRICT) {
-            const T d = x - y + P.p;
-            x = csub<T>(x + y, P.p);
-            y = csub<T>(shoup_mul<T, UNI>(d, w, ws, P.neg_p), P.p);
+            const T s = x + y;
+            const T d = (x - y) + (x < y ? P.two_p : (T)0);
+            x = s + (((s < x) | (s >= P.two_p)) ? P.neg_two_p : (T)0);
+            y = shoup_mul<T, UNI>(d, w, ws, P.neg_p);   // [0, 2p)
         } else {
             const T x0 = x;
             x = add_mod<T>(x0, y, P.p);
@@ -249,7 +254,7 @@ template <class T, int CLS> struct Bfly {
         if constexpr (CLS == CLS_LAZY) {
             x = shoup_mul<T, true>(x, P.n_inv, P.n_inv_shoup, P.neg_p);  // [0, 2p)
         } else if constexpr (CLS == CLS_STRICT) {
-            x = csub<T>(shoup_mul<T, true>(x, P.n_inv, P.n_inv_shoup, P.neg_p), P.p);
+            x = shoup_mul<T, true>(x, P.n_inv, P.n_inv_shoup, P.neg_p);  // [0, 2p)
         } else {
             x = mont_mul(x, P.n_inv, P.p, P.pinv_neg);  // n_inv field = N^-1 R^2: x / R * (N^-1 R^2) / R ... see mul_for_inv
         }
@@ -268,7 +273,7 @@ template <class T, int CLS> struct Bfly {
         return v;
     }
     static __device__ __forceinline__ T finish_inv(T v, const ModParams<T> &P) {
-        if constexpr (CLS == CLS_LAZY) return csub<T>(v, P.p);
+        if constexpr (CLS == CLS_LAZY || CLS == CLS_STRICT) return csub<T>(v, P.p);
         return v;
     }
 };
