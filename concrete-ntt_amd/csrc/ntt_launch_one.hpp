@@ -31,6 +31,13 @@ template <class K> static constexpr bool wp_eligible() {
 // workgroup of N / E <= 1024 threads, as many workgroups per CU as LDS and 16 wavefronts (128 VGPRs) allow
 template <class K> static constexpr bool wpg_eligible() { return K::NPASS > 1 && K::TPP >= 256 && K::TPP <= 1024 && K::LOGE <= 4; }
 
+// Instances of ntt_kernel_wpg that hipcc (ROCm 7.2) cannot fit into the 128 VGPRs of four waves per SIMD without
+// spilling.  A spilled register must never meet the asynchronous prefetch, so they are not instantiated at all;
+// tests/test_host_plan.py (zero spills) and tests/test_async_load_guard.py fail if this list falls behind the compiler.
+static constexpr bool wpg_spills(int logn, bool inv, int cls) {
+    return inv && ((cls == CLS_PM64 && logn == 14) || (cls == CLS_STRICT && logn >= 13));
+}
+
 template <class T, int LOGN, bool INV, int CLS, bool SUB>
 static hipError_t launch_one(T *data, const TwPair<T> *tw, const ModParams<T> &P, uint32_t nsub, uint32_t depth,
                              hipStream_t stream) {
@@ -48,12 +55,11 @@ static hipError_t launch_one(T *data, const TwPair<T> *tw, const ModParams<T> &P
         hipLaunchKernelGGL((ntt_kernel_wp<T, LOGN, INV, CLS, WP_BLOCK, BPC>), dim3(grid), dim3(WP_BLOCK), 0, stream, data,
                            tw, P, nsub);
     } else if constexpr (wpg_eligible<K>() && !SUB && sizeof(T) == 8 && CLS != CLS_GENERIC &&
-                         !(CLS == CLS_PM64 && INV && LOGN == 14)) {
+                         !wpg_spills(LOGN, INV, CLS)) {
         // Measured (profiles/r02_bench_grid_table.txt vs r01_v6): the persistent walk pays for the 64-bit classes whose
         // butterflies are cheap enough to expose memory latency (CLS_FP +30..45 %, lazy / strict forward +5..10 %); the
-        // 32-bit transforms and the Montgomery class ran 5..20 % slower on it and stay on ntt_kernel.  One CLS_PM64
-        // instance does not fit the 128 VGPRs of a 1024-thread workgroup without spilling (a spilled register must
-        // never meet the asynchronous prefetch) and stays there too.
+        // 32-bit transforms and the Montgomery class ran 5..20 % slower on it and stay on ntt_kernel, and so do the
+        // instances of wpg_spills().
         constexpr int WPB = K::TPP;
         using W = NttWp<T, LOGN, INV, CLS, WPB>;
         constexpr size_t LDS_BYTES = ((size_t)W::PPB << LOGN) * sizeof(T);

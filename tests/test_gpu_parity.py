@@ -144,6 +144,14 @@ def test_u64_every_class_vs_oracle(oracle, plans, oplans, p, n):
     _batch_case(oracle, plans, oplans, 64, n, p, 9, p % 1000 + n)
 
 
+@pytest.mark.parametrize("p", U64_PRIMES)
+@pytest.mark.parametrize("n", [2048, 8192, 16384, 32768])
+def test_u64_every_class_large_sizes_vs_oracle(oracle, plans, oplans, p, n):
+    """Every arithmetic class on the kernels of the larger sizes: the persistent L2-twiddle kernel (N = 4096 .. 16384 where
+    it is used), one polynomial per workgroup, and the global-stage path (N = 32768); ragged batch of 5."""
+    _batch_case(oracle, plans, oplans, 64, n, p, 5, p % 1000 + n)
+
+
 @pytest.mark.parametrize("p", U32_PRIMES)
 @pytest.mark.parametrize("n", [32, 256, 2048, 8192])
 def test_u32_every_class_vs_oracle(oracle, plans, oplans, p, n):
