@@ -913,11 +913,33 @@ extern "C" int cntt_native_inv_batch(const cntt_native_t *pl, void *value, void 
     return native_op(pl, 2, value, res, batch, where, (hipStream_t)st);
 }
 
+// bytes of workspace a polymul of `batch` products takes: the per-workgroup parking area of the large-n whole-product
+// kernel (native_fused.hpp) where that kernel runs, otherwise both operands' residue arrays of the composed pipeline
+static bool native_fusable(const cntt_native *pl, size_t batch) {
+    if (batch == 0 || batch >= ((size_t)1 << 32) || pl->info.is52) return false;
+    switch (pl->kind) {
+    case CNTT_NATIVE32_PLAN32:
+    case CNTT_NATIVE64_PLAN32:
+    case CNTT_NATIVE128_PLAN32:
+    case CNTT_NATIVE_BINARY32_PLAN32:
+    case CNTT_NATIVE_BINARY64_PLAN32:
+    case CNTT_NATIVE_BINARY128_PLAN32: return true;
+    default: return false;
+    }
+}
+static size_t native_park_bytes(const cntt_native *pl, size_t batch) {
+    if (!native_fusable(pl, batch)) return 0;
+    return sizeof(uint32_t) * native_fused_scratch_words((int)pl->kind, pl->p32[0]->logn, pl->info.nprimes, device_num_cus(),
+                                                        (uint32_t)batch);
+}
+static size_t native_workspace_bytes(const cntt_native *pl, size_t batch) {
+    const size_t park = native_park_bytes(pl, batch);
+    return park ? park : 2 * (size_t)pl->info.nprimes * batch * pl->n * pl->rbytes();
+}
 // caller holds pl->cache->mu
-static int native_workspace(const cntt_native *pl, size_t batch, Workspace **out) {
+static int native_workspace(const cntt_native *pl, size_t need, Workspace **out) {
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
-    const size_t need = 2 * (size_t)pl->info.nprimes * batch * pl->n * pl->rbytes();
     Workspace &w = pl->cache->ws[dev];
     if (w.bytes < need) {
         if (w.base) {
@@ -939,14 +961,14 @@ extern "C" int cntt_native_reserve(const cntt_native_t *pl, size_t batch) {
     if (!pl) return fail(CNTT_EINVAL, "plan is NULL");
     std::lock_guard<std::mutex> lk(pl->cache->mu);
     Workspace *w = nullptr;
-    return native_workspace(pl, batch, &w);
+    return native_workspace(pl, native_workspace_bytes(pl, batch), &w);
 }
 
 // negacyclic_polymul on device memory: src/native64.rs:1042-1069 batched
-// whole product in one kernel (native_fused.hpp) for the Plan32 kinds except native128, 32 <= n <= 4096
+// whole product in one kernel (native_fused.hpp) for the Plan32 kinds, 32 <= n <= 16384
 template <int KIND>
 static hipError_t native_fused_try(const cntt_native *pl, void *prod, const void *lhs, const void *rhs, size_t batch,
-                                   hipStream_t st, int *rc_out) {
+                                   uint32_t *park, hipStream_t st, int *rc_out) {
     constexpr int KP = NativeShape<KIND>::KP;
     FusedTables<KP> F{};
     for (int i = 0; i < KP; ++i) {
@@ -960,30 +982,40 @@ static hipError_t native_fused_try(const cntt_native *pl, void *prod, const void
         F.P[i] = pl->p32[(size_t)i]->mp;
     }
     const SplitArgs S = native_split_args(pl, nullptr);
-    return launch_native_fused<KIND>(pl->p32[0]->logn, prod, lhs, rhs, &F, S, pl->crt, (uint32_t)batch, st);
+    return launch_native_fused<KIND>(pl->p32[0]->logn, prod, lhs, rhs, &F, S, pl->crt, (uint32_t)batch, park, st);
+}
+// CNTT_OK: enqueued; FUSED_NONE: no whole-product kernel for this plan / size (the caller composes)
+static constexpr int FUSED_NONE = -1;
+static int native_fused_device(const cntt_native *pl, void *prod, const void *lhs, const void *rhs, size_t batch,
+                               uint32_t *park, hipStream_t st) {
+    int rc = CNTT_OK;
+    hipError_t e = hipErrorNotSupported;
+    switch (pl->kind) {
+    case CNTT_NATIVE32_PLAN32: e = native_fused_try<0>(pl, prod, lhs, rhs, batch, park, st, &rc); break;
+    case CNTT_NATIVE64_PLAN32: e = native_fused_try<1>(pl, prod, lhs, rhs, batch, park, st, &rc); break;
+    case CNTT_NATIVE128_PLAN32: e = native_fused_try<2>(pl, prod, lhs, rhs, batch, park, st, &rc); break;
+    case CNTT_NATIVE_BINARY32_PLAN32: e = native_fused_try<3>(pl, prod, lhs, rhs, batch, park, st, &rc); break;
+    case CNTT_NATIVE_BINARY64_PLAN32: e = native_fused_try<4>(pl, prod, lhs, rhs, batch, park, st, &rc); break;
+    case CNTT_NATIVE_BINARY128_PLAN32: e = native_fused_try<5>(pl, prod, lhs, rhs, batch, park, st, &rc); break;
+    default: break;
+    }
+    if (rc != CNTT_OK) return rc;
+    if (e == hipSuccess) return CNTT_OK;
+    if (e != hipErrorNotSupported) return fail(CNTT_EDEVICE, "fused polymul launch failed: %s", hipGetErrorString(e));
+    (void)hipGetLastError();
+    return FUSED_NONE;
 }
 
 static int native_polymul_device(const cntt_native *pl, void *prod, const void *lhs, const void *rhs, size_t batch,
                                  hipStream_t st) {
-    if (batch > 0 && batch < ((size_t)1 << 32) && !pl->info.is52) {
-        int rc = CNTT_OK;
-        hipError_t e = hipErrorNotSupported;
-        switch (pl->kind) {
-        case CNTT_NATIVE32_PLAN32: e = native_fused_try<0>(pl, prod, lhs, rhs, batch, st, &rc); break;
-        case CNTT_NATIVE64_PLAN32: e = native_fused_try<1>(pl, prod, lhs, rhs, batch, st, &rc); break;
-        case CNTT_NATIVE_BINARY32_PLAN32: e = native_fused_try<3>(pl, prod, lhs, rhs, batch, st, &rc); break;
-        case CNTT_NATIVE_BINARY64_PLAN32: e = native_fused_try<4>(pl, prod, lhs, rhs, batch, st, &rc); break;
-        case CNTT_NATIVE_BINARY128_PLAN32: e = native_fused_try<5>(pl, prod, lhs, rhs, batch, st, &rc); break;
-        default: break;
-        }
-        if (rc != CNTT_OK) return rc;
-        if (e == hipSuccess) return CNTT_OK;
-        if (e != hipErrorNotSupported) return fail(CNTT_EDEVICE, "fused polymul launch failed: %s", hipGetErrorString(e));
-        (void)hipGetLastError();
+    const size_t park = native_park_bytes(pl, batch);
+    if (park == 0 && native_fusable(pl, batch)) {
+        const int rc = native_fused_device(pl, prod, lhs, rhs, batch, nullptr, st);
+        if (rc != FUSED_NONE) return rc;
     }
     std::lock_guard<std::mutex> lk(pl->cache->mu);  // held while this call's launches are enqueued
     Workspace *ws = nullptr;
-    if (int rc = native_workspace(pl, batch, &ws)) return rc;
+    if (int rc = native_workspace(pl, native_workspace_bytes(pl, batch), &ws)) return rc;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(st, &cap);
     const bool capturing = cap != hipStreamCaptureStatusNone;
@@ -1000,6 +1032,10 @@ static int native_polymul_device(const cntt_native *pl, void *prod, const void *
         }
     } release{ws, st, !capturing};
     void *base = ws->base;
+    if (park) {  // n = 8192 / 16384: the persistent whole-product kernel, its workgroups parking residue tiles in the workspace
+        const int rc = native_fused_device(pl, prod, lhs, rhs, batch, (uint32_t *)base, st);
+        return rc == FUSED_NONE ? fail(CNTT_EDEVICE, "no whole-product kernel for n = %zu", pl->n) : rc;
+    }
     const int k = pl->info.nprimes;
     const size_t count = batch * pl->n, rb = count * pl->rbytes();
     void *L[10], *R[10];

@@ -1,9 +1,10 @@
 // Whole negacyclic_polymul of the native / native_binary Plan32 kinds in ONE kernel: for every
 // prime  split(lhs), split(rhs) -> two forward transforms -> pointwise product -> inverse transform (1/N folded into
-// its last stage)  with the residues kept in registers, then the mixed-radix CRT on the register tiles and one store
-// of the product word.  HBM traffic per product: lhs + rhs read ONCE (kept in registers across the primes), prod
-// written (the fused lower bound of SURVEY 8(d)); the unfused pipeline moves the 2k residue arrays through HBM
-// several times.
+// its last stage)  with the residues kept in registers, then the mixed-radix CRT on the residue tiles and one store
+// of the product word.  HBM traffic per product at n <= 4096: lhs + rhs read ONCE (kept in registers across the
+// primes), prod written (the fused lower bound of SURVEY 8(d)); the unfused pipeline moves the 2k residue arrays
+// through HBM several times.  n = 8192 / 16384 re-read the operands per prime and park residue tiles in a small
+// cache-resident scratch area (native_polymul_kernel_g).
 // Values are those of src/native64.rs:1042-1069 (and siblings): same split (% P_i), same transforms, same digits.
 // Twiddles come from the per-prime tables in global memory (L2): an LDS image per prime would not fit.
 #pragma once
@@ -15,6 +16,9 @@ namespace cntt {
 
 // digit structure of the reference plans handled here (host.hip NATIVE_KINDS; kind numbers of cntt_native_kind_t)
 template <int KIND> struct NativeShape;
+struct alignas(16) Word128 {  // u128 as Rust lays it out on x86-64: 16-byte little-endian (lo, hi)
+    uint64_t lo, hi;
+};
 template <> struct NativeShape<0> {  // native32::Plan32: three single-prime digits, u32 words
     using W = uint32_t;
     static constexpr int KP = 3, NG = 3;
@@ -30,6 +34,14 @@ template <> struct NativeShape<1> {  // native64::Plan32: digits P0, (P1,P2), (P
     static constexpr bool BINARY = false;
     static constexpr int ga(int g) { return g == 0 ? 0 : g == 1 ? 1 : 3; }
     static constexpr int gb(int g) { return g == 0 ? -1 : g == 1 ? 2 : 4; }
+};
+template <> struct NativeShape<2> {  // native128::Plan32: five two-prime digits (P0,P1) .. (P8,P9), u128 words
+    using W = Word128;
+    static constexpr int KP = 10, NG = 5;
+    static constexpr uint32_t PAIRS = 0b11111u;
+    static constexpr bool BINARY = false;
+    static constexpr int ga(int g) { return 2 * g; }
+    static constexpr int gb(int g) { return 2 * g + 1; }
 };
 template <> struct NativeShape<3> {  // native_binary32::Plan32
     using W = uint32_t;
@@ -48,9 +60,6 @@ template <> struct NativeShape<4> {  // native_binary64::Plan32
     static constexpr int gb(int) { return -1; }
 };
 
-struct alignas(16) Word128 {  // u128 as Rust lays it out on x86-64: 16-byte little-endian (lo, hi)
-    uint64_t lo, hi;
-};
 template <> struct NativeShape<5> {  // native_binary128::Plan32: digits P0, (P1,P2), (P3,P4), u128 words
     using W = Word128;
     static constexpr int KP = 5, NG = 3;
@@ -86,147 +95,242 @@ template <class W> __device__ __forceinline__ uint32_t split30(W w, const SplitA
 template <class SH> __device__ __forceinline__ typename SH::W crt_regs(const uint32_t (&r)[SH::KP], const CrtArgs &A) {
     constexpr int NG = SH::NG;
     uint64_t rg[NG];
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
+    static_for<0, NG>([&](auto gc) {
+        constexpr int g = gc.value;
         const uint64_t va = r[SH::ga(g)];
-        if (((SH::PAIRS >> g) & 1u) != 0u) {
-            const uint64_t pa = A.prime[SH::ga(g)], pb = A.prime[SH::gb(g) < 0 ? 0 : SH::gb(g)];
-            const uint64_t mb = r[SH::gb(g) < 0 ? 0 : SH::gb(g)];
+        if constexpr (((SH::PAIRS >> g) & 1u) != 0u) {
+            const uint64_t pa = A.prime[SH::ga(g)], pb = A.prime[SH::gb(g)];
+            const uint64_t mb = r[SH::gb(g)];
             const uint32_t d = (uint32_t)(2 * pb + mb - va);
             const uint64_t vb = shoup_mulmod32(d, (uint32_t)A.pair_inv[g], A.pair_inv_shoup[g], (uint32_t)pb);
             rg[g] = va + vb * pa;
         } else {
             rg[g] = va;
         }
-    }
+    });
     uint64_t v[NG];
     v[0] = rg[0];
-#pragma unroll
-    for (int g = 1; g < NG; ++g) {
+    // (static_for, not `#pragma unroll`: at five digits the nested loops were left rolled and v / rg went to scratch memory)
+    static_for<1, NG>([&](auto gc) {
+        constexpr int g = gc.value;
         if constexpr (SH::PAIRS == 0u) {
             const uint32_t m = (uint32_t)A.M[g];
             uint32_t acc = (uint32_t)v[g - 1];
             acc = umin<uint32_t>(acc, acc - m);
-#pragma unroll
-            for (int h = g - 2; h >= 0; --h) {
+            static_for<0, g - 1>([&](auto hc) {
+                constexpr int h = g - 2 - hc.value;
                 uint32_t t = shoup_mulmod32(acc, (uint32_t)A.Mmod[g][h], A.Mmod_shoup32[g][h], m);
                 uint32_t vh = (uint32_t)v[h];
                 vh = umin<uint32_t>(vh, vh - m);
                 t += vh;
                 acc = umin<uint32_t>(t, t - m);
-            }
+            });
             const uint32_t d = (uint32_t)rg[g] - acc + m;
             v[g] = shoup_mulmod32(d, (uint32_t)A.inv[g], A.inv_shoup32[g], m);
         } else {
-            // the digit moduli of these plans ascend (P0 < P1 P2 < P3 P4), so every digit v[h] < M[h] < M[g] and the
-            // group residue rg[g] < M[g] are already canonical modulo M[g]: no reduction (crt_kernel keeps a guarded
-            // `%` there; a 64-bit `%` expands to a long division routine, ruinous next to five live residue tiles)
+            // the digit moduli of these plans ascend (P0 < P1 P2 < P3 P4; P0 P1 < P2 P3 < ... for native128), so every digit
+            // v[h] < M[h] < M[g] and the group residue rg[g] < M[g] are already canonical modulo M[g]: no reduction
+            // (crt_kernel keeps a guarded `%` there; a 64-bit `%` expands to a long division routine, ruinous next to
+            // the live residue tiles)
             const uint64_t m = A.M[g];
             uint64_t acc = v[g - 1];
-#pragma unroll
-            for (int h = g - 2; h >= 0; --h) {
+            static_for<0, g - 1>([&](auto hc) {
+                constexpr int h = g - 2 - hc.value;
                 uint64_t t = shoup_mulmod(acc, A.Mmod[g][h], A.Mmod_shoup[g][h], m);
                 t += v[h];
                 acc = t >= m ? t - m : t;
-            }
+            });
             const uint64_t rr = rg[g];
             const uint64_t d = rr >= acc ? rr - acc : rr + m - acc;
             v[g] = shoup_mulmod(d, A.inv[g], A.inv_shoup[g], m);
         }
-    }
+    });
     const bool sign = v[NG - 1] > (A.M[NG - 1] / 2);
     if constexpr (sizeof(typename SH::W) == 16) {  // recombination modulo 2^128
         u128d pos = {v[0], 0};
-#pragma unroll
-        for (int g = 1; g < NG; ++g) pos = add128(pos, mul_64x128(v[g], A.prefix_lo[g], A.prefix_hi[g]));
+        static_for<1, NG>([&](auto gc) { pos = add128(pos, mul_64x128(v[gc.value], A.prefix_lo[gc.value], A.prefix_hi[gc.value])); });
         const u128d full = {A.prefix_lo[NG], A.prefix_hi[NG]};
         const u128d out = sign ? sub128(pos, full) : pos;
         return typename SH::W{out.lo, out.hi};
     } else {  // words of at most 64 bits: the recombination wraps modulo 2^64
         uint64_t pos = v[0];
-#pragma unroll
-        for (int g = 1; g < NG; ++g) pos += v[g] * A.prefix_lo[g];
+        static_for<1, NG>([&](auto gc) { pos += v[gc.value] * A.prefix_lo[gc.value]; });
         const uint64_t out = sign ? pos - A.prefix_lo[NG] : pos;
         return (typename SH::W)out;
     }
 }
 
-// PARK: the first PARK finished residue tiles wait for the CRT in LDS (thread-private slots, no synchronisation)
-// instead of registers -- five tiles of a 4096-point product do not fit the 256 VGPRs of two waves per SIMD.
-template <int KIND, int LOGN, int BLK, int PARK = 0>
+// One product (polynomial `sub` of the batch) by the TPP threads that own it.  All finished residue tiles but the last
+// wait for the CRT in thread-private "parking" slots instead of registers (measured faster than carrying them at every
+// size, and the only way five tiles fit at n = 4096).  Options:
+//   NF_GLOBAL   the slots live in a per-workgroup region of global memory (persistent kernel below) instead of LDS:
+//               n >= 8192, whose tiles no longer fit LDS next to the exchange buffer, and the ten-prime native128
+//   NF_KEEP_L/R the operand is read ONCE and stays in registers for all KP primes (a re-read per prime came back from
+//               HBM more often than not: rocprofv3 FETCH_SIZE showed 2.9x the operand bytes for native64 N=4096,
+//               profiles/r02); otherwise it is re-read per prime (L2 / Infinity Cache hits at best)
+//   NF_TW_CHUNK two twiddle loads in flight per stage instead of all (ntt_kernel.hpp stage<>): fewer live registers
+enum : int { NF_GLOBAL = 1, NF_KEEP_L = 2, NF_KEEP_R = 4, NF_TW_CHUNK = 8 };
+
+template <int KIND, int LOGN, int BLK, int OPT>
+__device__ __forceinline__ void native_product(typename NativeShape<KIND>::W *__restrict__ prod,
+                                               const typename NativeShape<KIND>::W *__restrict__ lhs,
+                                               const typename NativeShape<KIND>::W *__restrict__ rhs,
+                                               const FusedTables<NativeShape<KIND>::KP> &F, const SplitArgs &S,
+                                               const CrtArgs &C, uint32_t batch, uint32_t sub, uint32_t *lds_all,
+                                               uint32_t *park) {
+    using SH = NativeShape<KIND>;
+    using W = typename SH::W;
+    using Wf = NttWp<uint32_t, LOGN, false, CLS_LAZY, BLK, 1>;
+    using Wi = NttWp<uint32_t, LOGN, true, CLS_LAZY, BLK, 1>;
+    constexpr int E = Wf::E, TPP = Wf::TPP, NPASS = Wf::NPASS, KP = SH::KP, PARK = KP - 1;
+    constexpr bool GLOBAL = (OPT & NF_GLOBAL) != 0, KEEP_L = (OPT & NF_KEEP_L) != 0, KEEP_R = (OPT & NF_KEEP_R) != 0;
+    constexpr int TWC = (OPT & NF_TW_CHUNK) ? 2 : 0;
+    constexpr uint32_t FULL = Wf::FULL, RM0 = Wf::S::RMASK[0];
+    static_assert(RM0 == Wi::S::RMASK[NPASS - 1] && Wf::S::RMASK[NPASS - 1] == Wi::S::RMASK[0],
+                  "forward and inverse schedules must mirror each other");
+    static_assert(E % 4 == 0, "16-byte parking slots");
+    const uint32_t tid = threadIdx.x & (TPP - 1), pl = threadIdx.x / TPP;
+    uint32_t *lds = lds_all + ((size_t)pl << LOGN);
+    const uint32_t subc = sub < batch ? sub : batch - 1;  // ragged tail: recompute the last polynomial, store nothing
+    const W *lp = lhs + ((size_t)subc << LOGN), *rp = rhs + ((size_t)subc << LOGN);
+    const uint32_t ebase = pdep<FULL & ~RM0>(tid);
+    using RW = typename std::conditional<SH::BINARY, uint32_t, W>::type;
+    auto load_rhs = [&](int j, uint32_t eb) -> RW {
+        const W w = rp[eb | cdep((uint32_t)j, RM0)];
+        if constexpr (SH::BINARY) {  // `as u32`: src/native_binary64.rs:379-385, src/native_binary128.rs:100-106
+            if constexpr (sizeof(W) == 16) return (uint32_t)w.lo;
+            else return (uint32_t)w;
+        } else {
+            return w;
+        }
+    };
+    // global parking: tile i, coefficients 4q .. 4q+3 of this thread in one 16-byte slot, addressed as uniform base +
+    // 32-bit lane offset (the saddr form of global_load / global_store).  The lane offset is opaque to the compiler: it
+    // would otherwise hoist one 64-bit address per slot out of the product loop (~250 spilled registers).
+    uint32_t lane16 = threadIdx.x * 16u;
+    if constexpr (GLOBAL) asm volatile("" : "+v"(lane16));
+    auto gpark = [&](int i, int q) -> uint4 * {
+        return reinterpret_cast<uint4 *>(reinterpret_cast<char *>(park) + (size_t)(i * (E / 4) + q) * BLK * 16 + lane16);
+    };
+    uint32_t last[E];  // the tile of the last prime never leaves registers
+    W lw[KEEP_L ? E : 1];
+    RW rw[KEEP_R ? E : 1];
+    if constexpr (KEEP_L) {
+#pragma unroll
+        for (int j = 0; j < E; ++j) lw[j] = lp[ebase | cdep((uint32_t)j, RM0)];
+    }
+    if constexpr (KEEP_R) {
+#pragma unroll
+        for (int j = 0; j < E; ++j) rw[j] = load_rhs(j, ebase);
+    }
+    static_for<0, KP>([&](auto ic) {
+        constexpr int i = ic.value;
+        uint32_t a[E], b[E];
+        // The persistent kernel recomputes its twiddle and operand offsets per transform from opaque copies of the thread
+        // index: shared across the 3 KP inlined transforms and hoisted out of the product loop they cost hundreds of
+        // spilled registers.
+        uint32_t tidf = tid, tidg = tid, tidi = tid;
+        if constexpr (GLOBAL) asm volatile("" : "+v"(tidf), "+v"(tidg), "+v"(tidi));
+        const uint32_t eb_l = GLOBAL ? pdep<FULL & ~RM0>(tidf) : ebase, eb_r = GLOBAL ? pdep<FULL & ~RM0>(tidg) : ebase;
+#pragma unroll
+        for (int j = 0; j < E; ++j) a[j] = split30<W>(KEEP_L ? lw[KEEP_L ? j : 0] : lp[eb_l | cdep((uint32_t)j, RM0)], S, i);
+        Wf::template pass<0, false, false, true, TWC>(a, lds, tidf, F.twf[i], nullptr, F.P[i]);
+        Wf::wsync();
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            const RW w = KEEP_R ? rw[KEEP_R ? j : 0] : load_rhs(j, eb_r);
+            if constexpr (SH::BINARY) b[j] = w;
+            else b[j] = split30<W>(w, S, i);
+        }
+        Wf::template pass<0, false, false, true, TWC>(b, lds, tidg, F.twf[i], nullptr, F.P[i]);
+#pragma unroll
+        for (int j = 0; j < E; ++j) a[j] = mul_for_inv<uint32_t, CLS_LAZY>(a[j], b[j], F.P[i]);
+        Wf::wsync();
+        Wi::template pass<0, true, false, true, TWC>(a, lds, tidi, F.twi[i], nullptr, F.P[i]);
+        Wf::wsync();
+        if constexpr (i == KP - 1) {
+#pragma unroll
+            for (int j = 0; j < E; ++j) last[j] = a[j];
+        } else if constexpr (GLOBAL) {
+#pragma unroll
+            for (int q = 0; q < E / 4; ++q) *gpark(i, q) = uint4{a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]};
+        } else {
+#pragma unroll
+            for (int j = 0; j < E; ++j) park[((size_t)i * E + j) * BLK + threadIdx.x] = a[j];
+        }
+    });
+    if (sub < batch) {
+        W *op = prod + ((size_t)sub << LOGN);
+        if constexpr (GLOBAL) {
+            // (static_for: a rolled loop here would index `last` dynamically and send it to scratch memory)
+            static_for<0, E / 4>([&](auto qc) {
+                constexpr int q = qc.value;
+                uint4 t[PARK > 0 ? PARK : 1];
+#pragma unroll
+                for (int i = 0; i < PARK; ++i) t[i] = *gpark(i, q);
+                static_for<0, 4>([&](auto jc) {
+                    constexpr int jj = jc.value;
+                    uint32_t r[KP];
+#pragma unroll
+                    for (int i = 0; i < PARK; ++i) r[i] = jj == 0 ? t[i].x : jj == 1 ? t[i].y : jj == 2 ? t[i].z : t[i].w;
+                    r[KP - 1] = last[4 * q + jj];
+                    op[ebase | cdep((uint32_t)(4 * q + jj), RM0)] = crt_regs<SH>(r, C);
+                });
+                __builtin_amdgcn_sched_barrier(0);  // bounds the parked-tile loads in flight
+            });
+        } else {
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                uint32_t r[KP];
+#pragma unroll
+                for (int i = 0; i < PARK; ++i) r[i] = park[((size_t)i * E + j) * BLK + threadIdx.x];
+                r[KP - 1] = last[j];
+                op[ebase | cdep((uint32_t)j, RM0)] = crt_regs<SH>(r, C);
+            }
+        }
+    }
+}
+
+// products per workgroup / parked words per workgroup of a shape
+template <int KIND, int LOGN, int BLK> struct NativeTile {
+    using Wf = NttWp<uint32_t, LOGN, false, CLS_LAZY, BLK, 1>;
+    static constexpr int E = Wf::E, PPB = BLK / Wf::TPP, PARK = NativeShape<KIND>::KP - 1;
+    static constexpr size_t PARK_WORDS = (size_t)PARK * BLK * E;
+    static_assert(BLK % Wf::TPP == 0 && PPB >= 1, "whole products per workgroup");
+};
+
+// n <= 4096: one workgroup per PPB products, parked tiles in LDS, both operands kept in registers
+template <int KIND, int LOGN, int BLK>
 __global__ __launch_bounds__(BLK, 2) void native_polymul_kernel(typename NativeShape<KIND>::W *__restrict__ prod,
                                                              const typename NativeShape<KIND>::W *__restrict__ lhs,
                                                              const typename NativeShape<KIND>::W *__restrict__ rhs,
                                                              const FusedTables<NativeShape<KIND>::KP> F, const SplitArgs S,
                                                              const CrtArgs C, uint32_t batch) {
-    using SH = NativeShape<KIND>;
-    using W = typename SH::W;
-    using Wf = NttWp<uint32_t, LOGN, false, CLS_LAZY, BLK, 1>;
-    using Wi = NttWp<uint32_t, LOGN, true, CLS_LAZY, BLK, 1>;
-    constexpr int E = Wf::E, TPP = Wf::TPP, NPASS = Wf::NPASS, PPB = BLK / TPP, KP = SH::KP;
-    constexpr uint32_t FULL = Wf::FULL, RM0 = Wf::S::RMASK[0];
-    static_assert(RM0 == Wi::S::RMASK[NPASS - 1] && Wf::S::RMASK[NPASS - 1] == Wi::S::RMASK[0],
-                  "forward and inverse schedules must mirror each other");
-    __shared__ __attribute__((aligned(16))) uint32_t lds_all[(size_t)PPB << LOGN];
-    __shared__ uint32_t park[PARK > 0 ? PARK : 1][PARK > 0 ? (size_t)BLK * E : 1];
-    const uint32_t tid = threadIdx.x & (TPP - 1), pl = threadIdx.x / TPP;
-    uint32_t *lds = lds_all + ((size_t)pl << LOGN);
-    const uint32_t sub = blockIdx.x * PPB + pl;
-    const uint32_t subc = sub < batch ? sub : batch - 1;  // ragged tail: recompute the last polynomial, store nothing
-    const W *lp = lhs + ((size_t)subc << LOGN), *rp = rhs + ((size_t)subc << LOGN);
-    const uint32_t ebase = pdep<FULL & ~RM0>(tid);
-    uint32_t res[KP - PARK][E];
-    // Both operands are read ONCE and stay in registers for all KP primes (a re-read per prime came back from HBM
-    // more often than not: rocprofv3 FETCH_SIZE showed 2.9x the operand bytes for native64 N=4096 -- profiles/r02).
-    W lw[E];
-    typename std::conditional<SH::BINARY, uint32_t, W>::type rw[E];
-#pragma unroll
-    for (int j = 0; j < E; ++j) lw[j] = lp[ebase | cdep((uint32_t)j, RM0)];
-#pragma unroll
-    for (int j = 0; j < E; ++j) {
-        const W w = rp[ebase | cdep((uint32_t)j, RM0)];
-        if constexpr (SH::BINARY) {  // `as u32`: src/native_binary64.rs:379-385, src/native_binary128.rs:100-106
-            if constexpr (sizeof(W) == 16) rw[j] = (uint32_t)w.lo;
-            else rw[j] = (uint32_t)w;
-        } else {
-            rw[j] = w;
-        }
-    }
-    static_for<0, KP>([&](auto ic) {
-        constexpr int i = ic.value;
-        uint32_t a[E], b[E];
-#pragma unroll
-        for (int j = 0; j < E; ++j) a[j] = split30<W>(lw[j], S, i);
-        Wf::template pass<0, false, false>(a, lds, tid, F.twf[i], nullptr, F.P[i]);
-        Wf::wsync();
-#pragma unroll
-        for (int j = 0; j < E; ++j) {
-            if constexpr (SH::BINARY) b[j] = rw[j];
-            else b[j] = split30<W>(rw[j], S, i);
-        }
-        Wf::template pass<0, false, false>(b, lds, tid, F.twf[i], nullptr, F.P[i]);
-#pragma unroll
-        for (int j = 0; j < E; ++j) a[j] = mul_for_inv<uint32_t, CLS_LAZY>(a[j], b[j], F.P[i]);
-        Wf::wsync();
-        Wi::template pass<0, true, false>(a, lds, tid, F.twi[i], nullptr, F.P[i]);
-        Wf::wsync();
-        if constexpr (i < PARK) {
-#pragma unroll
-            for (int j = 0; j < E; ++j) park[i][(size_t)j * BLK + threadIdx.x] = a[j];
-        } else {
-#pragma unroll
-            for (int j = 0; j < E; ++j) res[i - PARK][j] = a[j];
-        }
-    });
-    if (sub < batch) {
-        W *op = prod + ((size_t)sub << LOGN);
-#pragma unroll
-        for (int j = 0; j < E; ++j) {
-            uint32_t r[KP];
-#pragma unroll
-            for (int i = 0; i < KP; ++i) r[i] = i < PARK ? park[i < PARK ? i : 0][(size_t)j * BLK + threadIdx.x] : res[i < PARK ? 0 : i - PARK][j];
-            op[ebase | cdep((uint32_t)j, RM0)] = crt_regs<SH>(r, C);
-        }
+    using T = NativeTile<KIND, LOGN, BLK>;
+    __shared__ __attribute__((aligned(16))) uint32_t lds_all[(size_t)T::PPB << LOGN];
+    __shared__ uint32_t park[T::PARK > 0 ? T::PARK_WORDS : 1];
+    native_product<KIND, LOGN, BLK, NF_KEEP_L | NF_KEEP_R>(prod, lhs, rhs, F, S, C, batch,
+                                                           blockIdx.x * T::PPB + threadIdx.x / T::Wf::TPP, lds_all, park);
+}
+
+// Persistent form: a grid sized to the device, every workgroup working through PPB products at a time and parking their
+// residue tiles in its own region of a global scratch area (grid x PARK_WORDS words, reused product after product, so it
+// stays in L2 / Infinity Cache).  n = 8192 / 16384 of every fused kind, and native128 (ten primes) at every size.
+template <int KIND, int LOGN, int BLK, int WPS, int OPT>
+__global__ __launch_bounds__(BLK, WPS) void native_polymul_kernel_g(typename NativeShape<KIND>::W *__restrict__ prod,
+                                                                const typename NativeShape<KIND>::W *__restrict__ lhs,
+                                                                const typename NativeShape<KIND>::W *__restrict__ rhs,
+                                                                const FusedTables<NativeShape<KIND>::KP> F,
+                                                                const SplitArgs S, const CrtArgs C, uint32_t batch,
+                                                                uint32_t *__restrict__ scratch) {
+    using T = NativeTile<KIND, LOGN, BLK>;
+    __shared__ __attribute__((aligned(16))) uint32_t lds_all[(size_t)T::PPB << LOGN];
+    uint32_t *park = scratch + (size_t)blockIdx.x * T::PARK_WORDS;
+    const uint32_t groups = (batch + T::PPB - 1) / T::PPB;
+    for (uint32_t g = blockIdx.x; g < groups; g += gridDim.x) {
+        native_product<KIND, LOGN, BLK, OPT | NF_GLOBAL>(prod, lhs, rhs, F, S, C, batch, g * T::PPB + threadIdx.x / T::Wf::TPP,
+                                                         lds_all, park);
+        T::Wf::wsync();  // the exchange buffer and the parked slots are reused by the next product
     }
 }
 

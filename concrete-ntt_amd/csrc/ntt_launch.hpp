@@ -70,8 +70,30 @@ struct ProductArgs;
 // ProductFusedTables.  hipErrorNotSupported for other sizes.
 hipError_t launch_product_fused2(int logn, int cls, bool inv, uint64_t *standard, uint32_t *res32, const void *tables,
                                  const ProductArgs &A, uint32_t batch, bool flag, hipStream_t st);
+// The persistent form of the kernel (n = 8192 / 16384 of every kind, native128 = kind 2 at every size) parks residue
+// tiles in `scratch` (native_fused_scratch_words() 32-bit words); the other shapes ignore it.
 template <int KIND>
 hipError_t launch_native_fused(int logn, void *prod, const void *lhs, const void *rhs, const void *tables, const SplitArgs &S,
-                               const CrtArgs &C, uint32_t batch, hipStream_t st);
+                               const CrtArgs &C, uint32_t batch, uint32_t *scratch, hipStream_t st);
+inline int device_num_cus() {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    return n;
+}
+inline bool native_fused_persistent(int kind, int logn) { return logn == 13 || logn == 14 || (kind == 2 && logn >= 5 && logn <= 12); }
+// words of one residue tile of a workgroup (256 threads x 16 coefficients hold 4096 / n products below n = 4096)
+inline size_t native_fused_tile_words(int logn) { return logn < 12 ? (size_t)4096 : (size_t)1 << logn; }
+// workgroups of the persistent kernel: what is resident on `ncu` compute units (two per unit; one 1024-thread workgroup at
+// n = 16384), at most one per group of products
+inline uint32_t native_fused_grid(int logn, int ncu, uint32_t batch) {
+    const size_t ppb = native_fused_tile_words(logn) >> logn;
+    const size_t groups = ((size_t)batch + ppb - 1) / ppb, g = (size_t)ncu * (logn == 14 ? 1u : logn == 13 ? 2u : 4u);
+    return (uint32_t)(g < groups ? g : groups);
+}
+inline size_t native_fused_scratch_words(int kind, int logn, int nprimes, int ncu, uint32_t batch) {
+    if (!native_fused_persistent(kind, logn)) return 0;
+    return (size_t)native_fused_grid(logn, ncu, batch) * (size_t)(nprimes - 1) * native_fused_tile_words(logn);
+}
 
 }  // namespace cntt

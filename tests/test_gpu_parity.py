@@ -482,6 +482,72 @@ def test_c3_c5_native_full_n(oracle):
         assert np.array_equal(to_host(dp, np.uint64), want), kind
 
 
+def _composed_polymul(torch, plan, cls, dl, dr, batch, n):
+    """split -> per-prime transforms -> pointwise -> inverse -> CRT through the plan's separate entry points"""
+    rl = [torch.empty(batch * n, dtype=torch.int32, device="cuda") for _ in range(cls.NPRIMES)]
+    rr = [torch.empty(batch * n, dtype=torch.int32, device="cuda") for _ in range(cls.NPRIMES)]
+    plan.fwd_batch(dl, rl)
+    plan.fwd_batch(dr, rr, binary=cls.BINARY)
+    for i in range(cls.NPRIMES):
+        plan.ntt(i).mul_assign_normalize_batch(rl[i], rr[i])
+    composed = torch.empty_like(dl)
+    plan.inv_batch(composed, rl)
+    return composed
+
+
+@pytest.mark.parametrize("n", [32, 256, 2048, 4096])
+def test_native128_polymul_persistent_kernel(oracle, n):
+    """native128::Plan32 (ten primes) runs the persistent whole-product kernel at every size, 4096 / n products per
+    workgroup.  A batch of more than 2 x 256 x 4096 / n products, not a multiple of the group: every workgroup loops and the
+    last group is ragged.  Samples against the oracle, every product against the composed pipeline."""
+    torch = _torch()
+    kind = "native128_plan32"
+    cls = NATIVE[kind]
+    plan, ref = cls.try_new(n), oracle.Native(kind, n)
+    batch = 2 * 256 * (4096 // n) + 4096 // n + 3
+    wpp = 2 * n
+    dl = torch.empty(batch * wpp, dtype=torch.int64, device="cuda")
+    dr = torch.empty_like(dl)
+    cntt.fill_uniform(dl, 0, 0x128A)
+    cntt.fill_uniform(dr, 0, 0x128B)
+    dp = torch.empty_like(dl)
+    plan.negacyclic_polymul_batch(dp, dl, dr)
+    for b in (0, 1, 4096 // n - 1, 4096 // n, batch // 2, batch - 2, batch - 1):
+        lhs = to_host(dl[b * wpp:(b + 1) * wpp], np.uint64).copy()
+        rhs = to_host(dr[b * wpp:(b + 1) * wpp], np.uint64).copy()
+        want = np.zeros(wpp, dtype=np.uint64)
+        ref.negacyclic_polymul(want, lhs, rhs)
+        assert np.array_equal(to_host(dp[b * wpp:(b + 1) * wpp], np.uint64), want), (n, b)
+    assert torch.equal(dp, _composed_polymul(torch, plan, cls, dl, dr, batch, n)), n
+
+
+@pytest.mark.parametrize("n", [8192, 16384])
+@pytest.mark.parametrize("kind", ["native32_plan32", "native64_plan32", "native128_plan32", "native_binary32_plan32",
+                                  "native_binary64_plan32", "native_binary128_plan32"])
+def test_native_polymul_large_n(oracle, kind, n):
+    """N = 8192 / 16384 run the persistent whole-product kernel whose workgroups park residue tiles in the plan's
+    workspace (csrc/native_fused.hpp, native_polymul_kernel_g).  A batch larger than the grid (every workgroup loops, the
+    last round is ragged): the first, the last and a few middle products against the oracle, and every product against the
+    composed split -> transforms -> pointwise -> CRT pipeline."""
+    torch = _torch()
+    cls = NATIVE[kind]
+    plan, ref = cls.try_new(n), oracle.Native(kind, n)
+    batch = 2 * 256 + 37
+    wpp = n * (2 if ref.word == 16 else 1)
+    per = [_native_inputs(oracle, kind, n, 31000 + b, cls.BINARY) for b in range(7)]
+    lhs = np.concatenate([per[b % 7][1] if b % 5 else np.roll(per[b % 7][1], b) for b in range(batch)])
+    rhs = np.concatenate([per[(b + 3) % 7][2] for b in range(batch)])
+    dl, dr = to_dev(lhs), to_dev(rhs)
+    dp = to_dev(np.zeros_like(lhs))
+    plan.negacyclic_polymul_batch(dp, dl, dr)
+    got = to_host(dp, lhs.dtype)
+    for b in (0, 1, 255, 256, 511, 512, batch - 1):
+        want = np.zeros(wpp, dtype=lhs.dtype)
+        ref.negacyclic_polymul(want, lhs[b * wpp:(b + 1) * wpp].copy(), rhs[b * wpp:(b + 1) * wpp].copy())
+        assert np.array_equal(got[b * wpp:(b + 1) * wpp], want), (kind, n, b)
+    assert torch.equal(dp, _composed_polymul(torch, plan, cls, dl, dr, batch, n)), (kind, n)
+
+
 def test_batch_calls_capture_into_a_hip_graph(oracle):
     """Device-resident _batch calls only enqueue (no allocation, no synchronisation), so a launch-bound sequence can be
     captured once into a hipGraph and replayed: fwd -> mul_assign_normalize -> inv, the fused mul_ntt, and a native
