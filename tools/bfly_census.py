@@ -19,27 +19,38 @@ SRC = r'''
 using namespace cntt;
 template <class T, int CLS, bool INV, int NB> __global__ void k(T *o, const T *in, const TwPair<T> *tw, ModParams<T> P) {
     const uint32_t t = threadIdx.x;
+#if %(BOX)s
+    // the form the kernels use for 32-bit lazy residues: values held in 64-bit "boxes" (BoxOps, ntt_arith.hpp)
+    uint64_t x = box32(in[t]), y = box32(in[t + 256]);
+#else
     T x = in[t], y = in[t + 256];
+#endif
     TwPair<T> w[NB];
 #pragma unroll
     for (int i = 0; i < NB; ++i) w[i] = tw[t + 64 * i];
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
+#if %(BOX)s
+        if constexpr (INV) BoxOps<CLS>::template inv<false>(x, y, w[i].w, w[i].ws, P);
+        else BoxOps<CLS>::template fwd<false>(x, y, w[i].w, w[i].ws, P);
+#else
         if constexpr (INV) Bfly<T, CLS>::template inv<false>(x, y, w[i].w, w[i].ws, P);
         else Bfly<T, CLS>::template fwd<false>(x, y, w[i].w, w[i].ws, P);
-        T s = x; x = y; y = s;   // alternate the roles so that both outputs stay live
+#endif
+        auto s = x; x = y; y = s;   // alternate the roles so that both outputs stay live
     }
-    o[t] = x; o[t + 256] = y;
+    o[t] = (T)x; o[t + 256] = (T)y;
 }
 template __global__ void k<%(T)s, %(CLS)s, %(INV)s, 4>(%(T)s *, const %(T)s *, const TwPair<%(T)s> *, ModParams<%(T)s>);
 template __global__ void k<%(T)s, %(CLS)s, %(INV)s, 12>(%(T)s *, const %(T)s *, const TwPair<%(T)s> *, ModParams<%(T)s>);
 '''
 
 
-def census(T, cls, inv):
+def census(T, cls, inv, box=False):
     with tempfile.TemporaryDirectory() as tmp:
         src = os.path.join(tmp, "c.hip")
-        open(src, "w").write(SRC % {"root": ROOT, "T": T, "CLS": cls, "INV": "true" if inv else "false"})
+        open(src, "w").write(SRC % {"root": ROOT, "T": T, "CLS": cls, "INV": "true" if inv else "false",
+                                   "BOX": "1" if box else "0"})
         out = os.path.join(tmp, "c.s")
         subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only", src, "-o", out],
                        check=True, stderr=subprocess.DEVNULL)
@@ -71,16 +82,18 @@ CASES = [("uint64_t", "CLS_LAZY", "u64 lazy (p < 2^62): Harvey butterfly, Shoup 
          ("uint64_t", "CLS_PM64", "u64 p = 2^64 - c (fold by c)"),
          ("uint64_t", "CLS_FP", "u64 p < 2^50 (double-precision FMA; range reductions not included: 3 per element every 5th fwd / 2nd inv stage)"),
          ("uint64_t", "CLS_FP51", "u64 p < 2^51 (double-precision FMA; reductions every 3rd fwd stage / every inv stage not included)"),
-         ("uint32_t", "CLS_LAZY", "u32 lazy (p < 2^30)"),
+         ("uint32_t", "CLS_LAZY", "u32 lazy (p < 2^30), plain 32-bit registers (not used by the kernels)"),
+         ("uint32_t", "CLS_LAZY", "u32 lazy (p < 2^30), boxed: x + y w - q p as two v_mad_u64_u32 on 64-bit boxes (what the kernels run)", True),
          ("uint32_t", "CLS_GENERIC", "u32 generic (Montgomery)")]
 
 if __name__ == "__main__":
     print(__doc__.split("\n\n")[0])
     print("s_nop = wait states hipcc inserts (two between a VALU write of VCC / an SGPR and its VALU read on gfx950; one after an")
     print("inline-asm block whose result the next instruction reads); they occupy the wave, not the VALU.")
-    for T, cls, title in CASES:
+    for case in CASES:
+        T, cls, title = case[:3]
         for inv in (False, True):
-            d = census(T, cls, inv)
+            d = census(T, cls, inv, len(case) > 3)
             valu = sum(v for k, v in d.items() if k.startswith("v_"))
             mul = sum(v for k, v in d.items() if re.match(r"v_(mad_u64_u32|mul_hi_u32|mul_lo_u32|mul_f64|fma_f64|fmac_f64)", k))
             print("\n%s, %s: %.2f VALU per butterfly (%.2f multiplies), %.2f s_nop" % (

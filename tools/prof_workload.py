@@ -85,5 +85,6 @@ if __name__ == "__main__":
     prime(prime32, 32, 1024, P30, 131072)
     native(native64.Plan32, 4096, 16384, False)          # C3
     native(native_binary64.Plan32, 2048, 65536, True)    # C5
+    native(native64.Plan32, 8192, 4096, False)           # native_polymul_kernel_g (persistent, global parking)
     chain(1024, P62, 6, 2, 8192)                          # ext_kernel_wp
     prod_plan(2048, [4294955009, 4294914049], 32768)      # product_fused
