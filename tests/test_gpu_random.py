@@ -113,7 +113,7 @@ def test_gpu_random_native_polymul(oracle, seed):
     rng = random.Random(5000 + seed)
     kind = NATIVE_KINDS[seed % len(NATIVE_KINDS)]
     cls = classes[kind]
-    n = 1 << rng.randint(5, 13)
+    n = 1 << rng.randint(5, 14)
     batch = rng.randint(1, 6)
     plan, ref = cls.try_new(n), oracle.Native(kind, n)
     assert plan is not None
