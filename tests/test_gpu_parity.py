@@ -548,6 +548,62 @@ def test_native_polymul_large_n(oracle, kind, n):
     assert torch.equal(dp, _composed_polymul(torch, plan, cls, dl, dr, batch, n)), (kind, n)
 
 
+@pytest.mark.parametrize("kind,n,batch", [("native64_plan32", 8192, 300), ("native128_plan32", 1024, 2100),
+                                          ("native64_plan52", 1024, 64)])
+def test_native_polymul_streams_and_threads_share_a_plan(kind, n, batch):
+    """One plan, one workspace (parking area of the persistent kernel / residue arrays of the composed pipeline), used from
+    two HIP streams and from two host threads at once: the library orders the calls that share the workspace
+    (csrc/host.hip, Workspace), so every result equals the one computed alone."""
+    import threading
+    torch = _torch()
+    cls = NATIVE[kind]
+    plan = cls.try_new(n)
+    wpp = n * (2 if cls.WORD == 16 else 1)
+    dt = torch.int32 if cls.WORD == 4 else torch.int64
+    sets = []
+    for k in range(4):
+        lhs = torch.empty(batch * wpp, dtype=dt, device="cuda")
+        rhs = torch.empty_like(lhs)
+        cntt.fill_uniform(lhs, 0, 0x57 + 2 * k)
+        cntt.fill_uniform(rhs, 0, 0x58 + 2 * k)
+        want = torch.empty_like(lhs)
+        plan.negacyclic_polymul_batch(want, lhs, rhs)
+        sets.append((lhs, rhs, want))
+    torch.cuda.synchronize()
+    # (1) two streams, calls interleaved from one thread
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [torch.zeros_like(sets[0][0]) for _ in range(4)]
+    for rep in range(6):
+        for k in range(4):
+            with torch.cuda.stream(streams[k % 2]):
+                plan.negacyclic_polymul_batch(outs[k], sets[k][0], sets[k][1])
+    torch.cuda.synchronize()
+    for k in range(4):
+        assert torch.equal(outs[k], sets[k][2]), (kind, "streams", k)
+    # (2) two host threads, each on its own stream
+    outs = [torch.zeros_like(sets[0][0]) for _ in range(4)]
+    errors = []
+
+    def worker(t):
+        try:
+            with torch.cuda.stream(streams[t]):
+                for rep in range(6):
+                    for k in (t, t + 2):
+                        plan.negacyclic_polymul_batch(outs[k], sets[k][0], sets[k][1])
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    torch.cuda.synchronize()
+    assert not errors, errors
+    for k in range(4):
+        assert torch.equal(outs[k], sets[k][2]), (kind, "threads", k)
+
+
 def test_batch_calls_capture_into_a_hip_graph(oracle):
     """Device-resident _batch calls only enqueue (no allocation, no synchronisation), so a launch-bound sequence can be
     captured once into a hipGraph and replayed: fwd -> mul_assign_normalize -> inv, the fused mul_ntt, and a native
