@@ -169,7 +169,8 @@ template <class SH> __device__ __forceinline__ typename SH::W crt_regs(const uin
 //               HBM more often than not: rocprofv3 FETCH_SIZE showed 2.9x the operand bytes for native64 N=4096,
 //               profiles/r02); otherwise it is re-read per prime (L2 / Infinity Cache hits at best)
 //   NF_TW_CHUNK two twiddle loads in flight per stage instead of all (ntt_kernel.hpp stage<>): fewer live registers
-enum : int { NF_GLOBAL = 1, NF_KEEP_L = 2, NF_KEEP_R = 4, NF_TW_CHUNK = 8 };
+//   NF_ROLL     the primes are a runtime loop instead of KP inlined copies of the three transforms
+enum : int { NF_GLOBAL = 1, NF_KEEP_L = 2, NF_KEEP_R = 4, NF_TW_CHUNK = 8, NF_ROLL = 16 };
 
 template <int KIND, int LOGN, int BLK, int OPT>
 __device__ __forceinline__ void native_product(typename NativeShape<KIND>::W *__restrict__ prod,
@@ -223,12 +224,12 @@ __device__ __forceinline__ void native_product(typename NativeShape<KIND>::W *__
 #pragma unroll
         for (int j = 0; j < E; ++j) rw[j] = load_rhs(j, ebase);
     }
-    static_for<0, KP>([&](auto ic) {
-        constexpr int i = ic.value;
-        uint32_t a[E], b[E];
+    // the inverse-transformed product residues of prime i -> a
+    auto one_prime = [&](int i, uint32_t (&a)[E]) {
+        uint32_t b[E];
         // The persistent kernel recomputes its twiddle and operand offsets per transform from opaque copies of the thread
-        // index: shared across the 3 KP inlined transforms and hoisted out of the product loop they cost hundreds of
-        // spilled registers.
+        // index: shared across the inlined transforms and hoisted out of the product loop they cost hundreds of spilled
+        // registers.
         uint32_t tidf = tid, tidg = tid, tidi = tid;
         if constexpr (GLOBAL) asm volatile("" : "+v"(tidf), "+v"(tidg), "+v"(tidi));
         const uint32_t eb_l = GLOBAL ? pdep<FULL & ~RM0>(tidf) : ebase, eb_r = GLOBAL ? pdep<FULL & ~RM0>(tidg) : ebase;
@@ -248,17 +249,38 @@ __device__ __forceinline__ void native_product(typename NativeShape<KIND>::W *__
         Wf::wsync();
         Wi::template pass<0, true, false, true, TWC>(a, lds, tidi, F.twi[i], nullptr, F.P[i]);
         Wf::wsync();
-        if constexpr (i == KP - 1) {
-#pragma unroll
-            for (int j = 0; j < E; ++j) last[j] = a[j];
-        } else if constexpr (GLOBAL) {
+    };
+    auto park_tile = [&](int i, const uint32_t (&a)[E]) {
+        if constexpr (GLOBAL) {
 #pragma unroll
             for (int q = 0; q < E / 4; ++q) *gpark(i, q) = uint4{a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]};
         } else {
 #pragma unroll
             for (int j = 0; j < E; ++j) park[((size_t)i * E + j) * BLK + threadIdx.x] = a[j];
         }
-    });
+    };
+    if constexpr ((OPT & NF_ROLL) != 0) {
+        // one copy of the three transforms for the parked primes (a runtime loop: tables and constants of prime i come
+        // from the kernel arguments by scalar loads) and one for the last: a fifth (a tenth for native128) of the code
+#pragma clang loop unroll(disable)
+        for (int i = 0; i < KP - 1; ++i) {
+            uint32_t a[E];
+            one_prime(i, a);
+            park_tile(i, a);
+        }
+        one_prime(KP - 1, last);
+    } else {
+        static_for<0, KP>([&](auto ic) {
+            constexpr int i = ic.value;
+            if constexpr (i == KP - 1) {
+                one_prime(i, last);
+            } else {
+                uint32_t a[E];
+                one_prime(i, a);
+                park_tile(i, a);
+            }
+        });
+    }
     if (sub < batch) {
         W *op = prod + ((size_t)sub << LOGN);
         if constexpr (GLOBAL) {
@@ -300,7 +322,7 @@ template <int KIND, int LOGN, int BLK> struct NativeTile {
 };
 
 // n <= 4096: one workgroup per PPB products, parked tiles in LDS, both operands kept in registers
-template <int KIND, int LOGN, int BLK>
+template <int KIND, int LOGN, int BLK, int OPT = 0>
 __global__ __launch_bounds__(BLK, 2) void native_polymul_kernel(typename NativeShape<KIND>::W *__restrict__ prod,
                                                              const typename NativeShape<KIND>::W *__restrict__ lhs,
                                                              const typename NativeShape<KIND>::W *__restrict__ rhs,
@@ -309,7 +331,7 @@ __global__ __launch_bounds__(BLK, 2) void native_polymul_kernel(typename NativeS
     using T = NativeTile<KIND, LOGN, BLK>;
     __shared__ __attribute__((aligned(16))) uint32_t lds_all[(size_t)T::PPB << LOGN];
     __shared__ uint32_t park[T::PARK > 0 ? T::PARK_WORDS : 1];
-    native_product<KIND, LOGN, BLK, NF_KEEP_L | NF_KEEP_R>(prod, lhs, rhs, F, S, C, batch,
+    native_product<KIND, LOGN, BLK, NF_KEEP_L | NF_KEEP_R | OPT>(prod, lhs, rhs, F, S, C, batch,
                                                            blockIdx.x * T::PPB + threadIdx.x / T::Wf::TPP, lds_all, park);
 }
 
