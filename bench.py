@@ -502,8 +502,8 @@ def run_rank(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)   # 0.12 s timed region: long enough for an SMI sampler to see it
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=65536, help="polynomials per GPU")
     ap.add_argument("--c4-batch", type=int, default=131072,
                     help="polynomials per GPU of the C4 extra (prime64 N=16384; 131072 = 2^20 / 8 GPUs = 16 GiB)")

@@ -60,7 +60,7 @@ inline hipError_t launch_ext_ntt(int logn, int cls, T *out, const T *terms, cons
     }
 }
 
-// Whole negacyclic_polymul of one native Plan32 kind (native_fused.hpp) for 32 <= n <= 4096; hipErrorNotSupported
+// Whole negacyclic_polymul of one native Plan32 kind (native_fused.hpp) for 32 <= n <= 16384; hipErrorNotSupported
 // otherwise.  `tables` points to the FusedTables<KP> of the plan (native_fused.hpp); KIND = cntt_native_kind_t value.
 struct SplitArgs;
 struct CrtArgs;
