@@ -64,7 +64,7 @@ static inline unsigned ew_grid(size_t work_items) {
 template <class T> struct DeviceTables {
     TwPair<T> *fwd = nullptr, *inv = nullptr;
     // plans whose LDS-resident transforms run in a 64-bit-only class: the same twiddles in that class's form --
-    // CLS_FP / CLS_FP51: (c, c / p) doubles, c centred in (-p/2, p/2];  CLS_PM64: plain residues
+    // CLS_FP / CLS_FP51: (c, c / p) doubles, c centred in (-p/2, p/2];  CLS_PM64: plain residues;  CLS_FPW: c as one double
     TwPair<T> *fwd_fp = nullptr, *inv_fp = nullptr;
 };
 
@@ -206,6 +206,22 @@ template <class T, class PlanT> static int plan_new(size_t n, T p, PlanT **out) 
             mp.fp_last_w_q = host::double_bits(wl / pd);
         }
     }
+    // CLS_FPW: 32-bit words, p >= 2^31 (no lazy headroom in 32 bits: the Montgomery class otherwise): the LDS-resident
+    // transforms run on doubles (ntt_arith.hpp).  CNTT_DISABLE_FP=1 keeps the Montgomery class here too.
+    if constexpr (B == 32) {
+        const char *off = std::getenv("CNTT_DISABLE_FP");
+        if (mp.cls == CLS_GENERIC && !(off && off[0] == '1')) {
+            mp.fp = (uint32_t)CLS_FPW;
+            const double pd = (double)p64;
+            mp.fp_p = host::double_bits(pd);
+            mp.fp_pinv = host::double_bits(1.0 / pd);
+            const double ni = host::centred(pl->n_inv, p64), wl = host::centred(w_last, p64);
+            mp.fp_n_inv = host::double_bits(ni);
+            mp.fp_n_inv_q = host::double_bits(ni / pd);
+            mp.fp_last_w = host::double_bits(wl);
+            mp.fp_last_w_q = host::double_bits(wl / pd);
+        }
+    }
     // CLS_PM64: p = 2^64 - c with c < 2^32 (Solinas, and the largest primes below 2^64).  CNTT_DISABLE_PM64=1 keeps the
     // Montgomery class (A/B measurements and tests).
     mp.pm_c = 0;
@@ -223,14 +239,21 @@ template <class T, class PlanT> static int plan_new(size_t n, T p, PlanT **out) 
     return CNTT_OK;
 }
 
-static bool alt_tables(int cls) { return is_fp_class(cls) || cls == CLS_PM64; }
+static bool alt_tables(int cls) { return is_fp_class(cls) || cls == CLS_PM64 || cls == CLS_FPW; }
 
 // transform class of the LDS-resident kernels for this plan (the global-stage path of larger sizes is integer-only)
 template <class T> static int transform_class(const PrimePlan<T> *pl) {
     if (pl->logn > MaxLdsLogN<T>::value) return (int)pl->mp.cls;
+    if (pl->mp.fp == CLS_FPW && pl->logn > MAX_FPW_LOGN) return (int)pl->mp.cls;
     if (pl->mp.fp) return (int)pl->mp.fp;
     if (pl->mp.pm_c) return (int)CLS_PM64;
     return (int)pl->mp.cls;
+}
+
+// class of the fused product / chain kernels: they have no CLS_FPW form (their pointwise steps work on 32-bit words)
+template <class T> static int fused_class(const PrimePlan<T> *pl) {
+    const int c = transform_class(pl);
+    return c == CLS_FPW ? (int)pl->mp.cls : c;
 }
 
 // per-device table replica, created on first use under the cache mutex
@@ -268,10 +291,10 @@ template <class T> static int device_tables(const PrimePlan<T> *pl, DeviceTables
     }
     HIP_TRY(hipMemcpy(t.fwd, f.data(), n * sizeof(TwPair<T>), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(t.inv, i.data(), n * sizeof(TwPair<T>), hipMemcpyHostToDevice));
-    if constexpr (sizeof(T) == 8) {
-        if (pl->mp.fp || pl->mp.pm_c) {
-            const double pd = (double)p64;
-            for (size_t k = 0; k < n; ++k) {
+    if (pl->mp.fp || pl->mp.pm_c) {
+        const double pd = (double)p64;
+        for (size_t k = 0; k < n; ++k) {
+            if constexpr (sizeof(T) == 8) {
                 if (pl->mp.fp) {
                     const double cf = host::centred((uint64_t)pl->twid[k], p64), ci = host::centred((uint64_t)pl->inv_twid[k], p64);
                     f[k].w = host::double_bits(cf);
@@ -284,17 +307,25 @@ template <class T> static int device_tables(const PrimePlan<T> *pl, DeviceTables
                     i[k].w = pl->inv_twid[k];
                     i[k].ws = 0;
                 }
+            } else {  // CLS_FPW: the 8-byte entry is the centred twiddle as a double (w = low, ws = high word)
+                (void)pd;
+                const uint64_t bf = host::double_bits(host::centred((uint64_t)pl->twid[k], p64));
+                const uint64_t bi = host::double_bits(host::centred((uint64_t)pl->inv_twid[k], p64));
+                f[k].w = (T)bf;
+                f[k].ws = (T)(bf >> 32);
+                i[k].w = (T)bi;
+                i[k].ws = (T)(bi >> 32);
             }
-            if (hipMalloc((void **)&t.fwd_fp, n * sizeof(TwPair<T>)) != hipSuccess ||
-                hipMalloc((void **)&t.inv_fp, n * sizeof(TwPair<T>)) != hipSuccess) {
-                (void)hipFree(t.fwd);
-                (void)hipFree(t.inv);
-                (void)hipFree(t.fwd_fp);
-                return fail(CNTT_ENOMEM, "hipMalloc of the twiddle tables failed");
-            }
-            HIP_TRY(hipMemcpy(t.fwd_fp, f.data(), n * sizeof(TwPair<T>), hipMemcpyHostToDevice));
-            HIP_TRY(hipMemcpy(t.inv_fp, i.data(), n * sizeof(TwPair<T>), hipMemcpyHostToDevice));
         }
+        if (hipMalloc((void **)&t.fwd_fp, n * sizeof(TwPair<T>)) != hipSuccess ||
+            hipMalloc((void **)&t.inv_fp, n * sizeof(TwPair<T>)) != hipSuccess) {
+            (void)hipFree(t.fwd);
+            (void)hipFree(t.inv);
+            (void)hipFree(t.fwd_fp);
+            return fail(CNTT_ENOMEM, "hipMalloc of the twiddle tables failed");
+        }
+        HIP_TRY(hipMemcpy(t.fwd_fp, f.data(), n * sizeof(TwPair<T>), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(t.inv_fp, i.data(), n * sizeof(TwPair<T>), hipMemcpyHostToDevice));
     }
     pl->cache->per_device[dev] = t;
     *out = t;
@@ -373,7 +404,7 @@ template <class T> static int mul_ntt_device(const PrimePlan<T> *pl, T *lhs, con
     if (batch >= ((size_t)1 << 32)) return fail(CNTT_EINVAL, "batch too large for one launch");
     DeviceTables<T> t;
     if (int rc = device_tables(pl, &t)) return rc;
-    const int tcls = transform_class(pl);
+    const int tcls = fused_class(pl);
     const hipError_t e = launch_mul_ntt<T>(pl->logn, tcls, lhs, rhs, alt_tables(tcls) ? t.fwd_fp : t.fwd,
                                            alt_tables(tcls) ? t.inv_fp : t.inv, pl->mp, (uint32_t)batch, st);
     if (e == hipSuccess) return CNTT_OK;
@@ -399,7 +430,7 @@ static int external_product_device(const PrimePlan<T> *pl, T *out, const T *term
     }
     DeviceTables<T> t;
     if (int rc = device_tables(pl, &t)) return rc;
-    const int tcls = transform_class(pl);
+    const int tcls = fused_class(pl);
     const hipError_t e = launch_ext_ntt<T>(pl->logn, tcls, out, terms, key, alt_tables(tcls) ? t.fwd_fp : t.fwd,
                                            alt_tables(tcls) ? t.inv_fp : t.inv, pl->mp, (uint32_t)batch, (uint32_t)nterms,
                                            (uint32_t)nout, accumulate, st);

@@ -27,7 +27,7 @@
 
 namespace cntt {
 
-enum : int { CLS_LAZY = 0, CLS_STRICT = 1, CLS_GENERIC = 2, CLS_FP = 3, CLS_FP51 = 4, CLS_PM64 = 5 };
+enum : int { CLS_LAZY = 0, CLS_STRICT = 1, CLS_GENERIC = 2, CLS_FP = 3, CLS_FP51 = 4, CLS_PM64 = 5, CLS_FPW = 6 };
 
 // One table entry: the twiddle and its Shoup companion floor(w * 2^B / p) (CLS_GENERIC: w holds
 // w * 2^B mod p and ws is unused).  Interleaved so that one 16-byte (u64) / 8-byte (u32) load
@@ -50,10 +50,11 @@ template <class T> struct ModParams {
                            // fused product kernel normalises inside the last inverse stage (Bfly::inv_norm)
     // CLS_FP (64-bit words, p < 2^50): bit patterns of doubles -- p, 1/p, and the plan constants in centred
     // form c in (-p/2, p/2] with their quotient companions c/p
-    T fp_p, fp_pinv, fp_n_inv, fp_n_inv_q, fp_last_w, fp_last_w_q;
+    // (also CLS_FPW: 32-bit words whose transforms run on doubles)
+    uint64_t fp_p, fp_pinv, fp_n_inv, fp_n_inv_q, fp_last_w, fp_last_w_q;
     uint32_t big_q;        // floor(log2 p) + 1
     uint32_t cls;          // integer arithmetic class (pointwise kernels, global stages, every non-FP transform)
-    uint32_t fp;           // CLS_FP / CLS_FP51: class of the LDS-resident transforms of this plan (0: cls)
+    uint32_t fp;           // CLS_FP / CLS_FP51 / CLS_FPW: class of the LDS-resident transforms of this plan (0: cls)
     // CLS_PM64 (p = 2^64 - c, c < 2^32): c, and the plan constants as plain residues
     uint32_t pm_c;         // 0: not such a modulus
     T pm_n_inv, pm_last_w;
@@ -262,7 +263,7 @@ template <class T, int CLS> struct Bfly {
     static constexpr bool IS_FP = false;
     static constexpr bool FUSED_LAZY = false;  // the fused kernels hand canonical values to the pointwise product
     // a word as loaded from memory -> the class's register form (identity for the integer classes)
-    static __device__ __forceinline__ T load_fix(T v) { return v; }
+    static __device__ __forceinline__ T load_fix(T v, const ModParams<T> &) { return v; }
     static __device__ __forceinline__ T reduce(T v, const ModParams<T> &) { return v; }
     // an accumulator of the fused chains -> what the inverse transform's first stage accepts
     static __device__ __forceinline__ T pre_inverse(T v, const ModParams<T> &) { return v; }
@@ -306,6 +307,8 @@ template <bool UNI> __device__ __forceinline__ uint64_t mul_box(uint32_t a, uint
 template <int CLS> struct BoxOps {
     template <class T> struct USE { static constexpr bool value = sizeof(T) == 4 && CLS == CLS_LAZY; };
     using P32 = ModParams<uint32_t>;
+    static __device__ __forceinline__ uint64_t box(uint32_t v, const P32 &) { return box32(v); }
+    static __device__ __forceinline__ uint32_t unbox(uint64_t c, const P32 &) { return (uint32_t)c; }
     // (x, y) <- (x + w y, x - w y), values in [0, 4p)
     template <bool UNI> static __device__ __forceinline__ void fwd(uint64_t &X, uint64_t &Y, uint32_t w, uint32_t ws, const P32 &P) {
         const uint32_t x = umin<uint32_t>((uint32_t)X, (uint32_t)X - P.two_p);
@@ -373,7 +376,8 @@ struct Fp {
         const double r = __fma_rn(-q, p, h);
         return __dadd_rn(r, l);
     }
-    // a * b mod p for two data values, |a| <= p/2, 0 <= b < p < 2^51: |result| <= 0.875 p
+    // a * b mod p with the quotient from the rounded product (two data values, |a| <= p/2, 0 <= b < p < 2^51: |result| <=
+    // 0.875 p; CLS_FPW: any |a b / p| < 2^47)
     static __device__ __forceinline__ double mul_data(double a, double b, double p, double pinv) {
         const double h = __dmul_rn(a, b);
         const double q = __builtin_rint(__dmul_rn(h, pinv));
@@ -397,7 +401,7 @@ template <class T, int HEAD> struct BflyFp {
     static constexpr int FWD_REDUCE_EVERY = HEAD >= 8 ? 5 : 3;   // forward: every value, after this many stages
     static constexpr int INV_REDUCE_EVERY = HEAD >= 8 ? 2 : 1;   // inverse: the sums, after this many stages
     static constexpr int ACC_REDUCE_EVERY = HEAD >= 8 ? 8 : 2;   // mul_accumulate chains: products (<= 0.875 p) per reduction
-    static __device__ __forceinline__ T load_fix(T v) { return Fp::u(Fp::from_word(v)); }
+    static __device__ __forceinline__ T load_fix(T v, const ModParams<T> &) { return Fp::u(Fp::from_word(v)); }
     static __device__ __forceinline__ T reduce(T v, const ModParams<T> &P) {
         return Fp::u(Fp::reduce(Fp::d(v), Fp::d(P.fp_p), Fp::d(P.fp_pinv)));
     }
@@ -428,6 +432,64 @@ template <class T, int HEAD> struct BflyFp {
 template <class T> struct Bfly<T, CLS_FP> : BflyFp<T, 8> {};
 template <class T> struct Bfly<T, CLS_FP51> : BflyFp<T, 4> {};
 __host__ __device__ constexpr bool is_fp_class(int cls) { return cls == CLS_FP || cls == CLS_FP51; }
+
+// ---------------------------------------------------------------------------------------------
+// CLS_FPW: 32-bit WORDS whose transforms run on doubles (every odd p < 2^32; used for p >= 2^31, the moduli that have no
+// lazy headroom in 32 bits and would otherwise take the Montgomery class at 20.6 instructions per butterfly).
+//
+// Inside a pass's register stages a coefficient is a double in a 64-bit "box" (as for the lazy 32-bit class, BoxOps):
+// an exact integer v = residue (mod p).  Memory holds canonical words; LDS between the passes holds the CENTRED residue
+// (|v| <= (p + 1) / 2 < 2^31) as an int32 bit pattern, so a pass boundary costs v_cvt_f64_i32 on the way in and
+// reduce + v_cvt_i32_f64 on the way out.  A twiddle-table entry (8 bytes, like every TwPair<uint32_t>) IS the centred
+// twiddle as a double (csrc/host.hip): no conversion, and no quotient companion -- the quotient comes from the product,
+//     h = fl(y c)   q = rint(fl(h / p))   l = fma(y, c, -h)   r = fma(-q, p, h)   t = r + l        (Fp::mul_data)
+// eight instructions per butterfly with the two sums.
+// With p < 2^32 the doubles have H = 2^53 / p > 2^21 units of p of headroom, so NO range reduction is needed inside a
+// transform: forward bounds grow by 1/2 + B / H per stage (<= 9 p after 16 stages), inverse sums double per stage
+// (<= 2^15 p for the largest LDS-resident size) and the quotient estimate's error stays below 2^-5
+// (|y c / p| <= 2^15 * 2^31 at 3 * 2^-53 relative), i.e. |t| <= (1/2 + 2^-5) p; h - q p = t - l is an integer far below
+// 2^53, so r is exact.
+// ---------------------------------------------------------------------------------------------
+template <> struct BoxOps<CLS_FPW> {
+    template <class T> struct USE { static constexpr bool value = sizeof(T) == 4; };
+    using P32 = ModParams<uint32_t>;
+    static __device__ __forceinline__ double tw(uint32_t lo, uint32_t hi) { return Fp::d(((uint64_t)hi << 32) | lo); }
+    static __device__ __forceinline__ uint64_t box(uint32_t v, const P32 &) { return Fp::u((double)(int32_t)v); }  // v_cvt_f64_i32
+    static __device__ __forceinline__ uint32_t unbox(uint64_t c, const P32 &P) {
+        return (uint32_t)(int32_t)Fp::reduce(Fp::d(c), Fp::d(P.fp_p), Fp::d(P.fp_pinv));   // |.| <= (p + 1) / 2 < 2^31
+    }
+    template <bool UNI> static __device__ __forceinline__ void fwd(uint64_t &X, uint64_t &Y, uint32_t w, uint32_t ws, const P32 &P) {
+        const double x = Fp::d(X);
+        const double t = Fp::mul_data(Fp::d(Y), tw(w, ws), Fp::d(P.fp_p), Fp::d(P.fp_pinv));
+        X = Fp::u(__dadd_rn(x, t));
+        Y = Fp::u(__dadd_rn(x, -t));
+    }
+    template <bool UNI> static __device__ __forceinline__ void inv(uint64_t &X, uint64_t &Y, uint32_t w, uint32_t ws, const P32 &P) {
+        const double x = Fp::d(X), y = Fp::d(Y);
+        X = Fp::u(__dadd_rn(x, y));
+        Y = Fp::u(Fp::mul_data(__dadd_rn(x, -y), tw(w, ws), Fp::d(P.fp_p), Fp::d(P.fp_pinv)));
+    }
+    static __device__ __forceinline__ void inv_norm(uint64_t &X, uint64_t &Y, const P32 &P) {
+        const double x = Fp::d(X), y = Fp::d(Y), p = Fp::d(P.fp_p), pinv = Fp::d(P.fp_pinv);
+        X = Fp::u(Fp::mul_data(__dadd_rn(x, y), Fp::d(P.fp_n_inv), p, pinv));
+        Y = Fp::u(Fp::mul_data(__dadd_rn(x, -y), Fp::d(P.fp_last_w), p, pinv));
+    }
+};
+// the word-level hooks of the class (the butterflies live in BoxOps<CLS_FPW>: the kernels never run them on bare words)
+template <> struct Bfly<uint32_t, CLS_FPW> {
+    using T = uint32_t;
+    static constexpr bool IS_FP = false;      // no in-transform range reductions (see above)
+    static constexpr bool FUSED_LAZY = false;
+    // canonical word -> centred residue as an int32 pattern
+    static __device__ __forceinline__ T load_fix(T v, const ModParams<T> &P) { return v > (P.p >> 1) ? v - P.p : v; }
+    static __device__ __forceinline__ T reduce(T v, const ModParams<T> &) { return v; }
+    static __device__ __forceinline__ T pre_inverse(T v, const ModParams<T> &) { return v; }
+    // centred int32 pattern -> canonical word
+    static __device__ __forceinline__ T finish_fwd(T v, const ModParams<T> &P) {
+        return v + (P.p & (T)((int32_t)v >> 31));
+    }
+    static __device__ __forceinline__ T finish_inv(T v, const ModParams<T> &P) { return finish_fwd(v, P); }
+};
 
 // ---------------------------------------------------------------------------------------------
 // CLS_PM64: p = 2^64 - c, c < 2^32 (64-bit words)
@@ -484,7 +546,7 @@ template <class T> struct Bfly<T, CLS_PM64> {
     static_assert(sizeof(T) == 8, "CLS_PM64 is a 64-bit class");
     static constexpr bool IS_FP = false;
     static constexpr bool FUSED_LAZY = true;  // products take any representative: fused kernels skip finish_fwd
-    static __device__ __forceinline__ T load_fix(T v) { return v; }
+    static __device__ __forceinline__ T load_fix(T v, const ModParams<T> &) { return v; }
     static __device__ __forceinline__ T reduce(T v, const ModParams<T> &) { return v; }
     static __device__ __forceinline__ T canon(T v, const ModParams<T> &P) { return v >= P.p ? v + P.pm_c : v; }  // v - p
     template <bool UNI> static __device__ __forceinline__ T mulc(T y, T w, const ModParams<T> &P) {

@@ -420,10 +420,10 @@ struct NttKernel {
         if constexpr (BoxOps<CLS>::template USE<T>::value) {
             uint64_t c[E];
 #pragma unroll
-            for (int j = 0; j < E; ++j) c[j] = box32((uint32_t)r[j]);
+            for (int j = 0; j < E; ++j) c[j] = BoxOps<CLS>::box((uint32_t)r[j], P);
             stages_r<K, GI, IMG, NORM, TWC, uint64_t>(c, ebase, qpre, depth, tw, P, tid, img);
 #pragma unroll
-            for (int j = 0; j < E; ++j) r[j] = (T)(uint32_t)c[j];
+            for (int j = 0; j < E; ++j) r[j] = (T)BoxOps<CLS>::unbox(c[j], P);
         } else {
             stages_r<K, GI, IMG, NORM, TWC, T>(r, ebase, qpre, depth, tw, P, tid, img);
         }
@@ -438,7 +438,7 @@ struct NttKernel {
         if constexpr (K == 0) {
             if (active) gather<RM>(r, (const T *)g, ebase, false);
 #pragma unroll
-            for (int j = 0; j < E; ++j) r[j] = Bfly<T, CLS>::load_fix(r[j]);
+            for (int j = 0; j < E; ++j) r[j] = Bfly<T, CLS>::load_fix(r[j], P);
         } else {
             gather<RM>(r, (const T *)lds, ebase, true);
         }
@@ -580,7 +580,7 @@ struct NttWp : NttKernel<T, LOGN, INV, CLS, false, FAM> {
                                                 ((pln << LOGN) + ebIO) * (uint32_t)sizeof(T));
             }
 #pragma unroll
-            for (int j = 0; j < E; ++j) r[j] = Bfly<T, CLS>::load_fix(r[j]);  // memory word -> register form
+            for (int j = 0; j < E; ++j) r[j] = Bfly<T, CLS>::load_fix(r[j], P);  // memory word -> register form
             if constexpr (RM0 != IO_RM) {  // input transpose
                 B::template scatter<IO_RM>(r, lds, ebIO, true);
                 wsync();
@@ -683,7 +683,7 @@ struct MulWp {
                                                  ((pln << LOGN) + ebaseIO) * (uint32_t)sizeof(T));
             }
 #pragma unroll
-            for (int j = 0; j < E; ++j) r[j] = Bfly<T, CLS>::load_fix(r[j]);
+            for (int j = 0; j < E; ++j) r[j] = Bfly<T, CLS>::load_fix(r[j], P);
             if constexpr (RM0 != IO_RM) {
                 FB::template scatter<IO_RM>(r, lds, ebaseIO, true);
                 F::wsync();
@@ -813,7 +813,7 @@ struct ExtWp {
                 T nx[E];
                 FB::template gather<IO_RM>(nx, tb + ((size_t)jn << LOGN), ebaseIO, false);
 #pragma unroll
-                for (int e = 0; e < E; ++e) r[e] = Bfly<T, CLS>::load_fix(r[e]);
+                for (int e = 0; e < E; ++e) r[e] = Bfly<T, CLS>::load_fix(r[e], P);
                 if constexpr (RM0 != IO_RM) {
                     FB::template scatter<IO_RM>(r, lds, ebaseIO, true);
                     F::wsync();

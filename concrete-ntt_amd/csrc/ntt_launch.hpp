@@ -12,6 +12,8 @@ namespace cntt {
 template <class T> struct MaxLdsLogN;
 template <> struct MaxLdsLogN<uint64_t> { static constexpr int value = 14; };
 template <> struct MaxLdsLogN<uint32_t> { static constexpr int value = 15; };
+// largest size whose transforms run in CLS_FPW: the 32768-point kernel (one 1024-thread workgroup, 128 VGPRs) would spill
+constexpr int MAX_FPW_LOGN = 14;
 template <class T> struct MinLogN;
 template <> struct MinLogN<uint64_t> { static constexpr int value = 4; };  // src/prime64.rs:709
 template <> struct MinLogN<uint32_t> { static constexpr int value = 5; };  // src/prime32.rs:635

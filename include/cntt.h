@@ -62,8 +62,8 @@ typedef struct cntt_plan_info {
     uint64_t root;      /* the primitive 2n-th root w chosen by src/roots.rs:68-91 */
     int32_t has_shoup;  /* 0 when modulus >= 2^(B-1): no Shoup tables (src/prime64.rs:729-736) */
     int32_t arith_class; /* device arithmetic class of the transforms: 0 lazy (p < 2^(B-2)), 1 strict, 2 generic,
-                          3 / 4 double-precision FMA (64-bit words, p < 2^50 / p < 2^51), 5 pseudo-Mersenne 2^64 - c, c < 2^32
-                          (3-5: sizes that live in LDS) */
+                          3 / 4 double-precision FMA (64-bit words, p < 2^50 / p < 2^51), 5 pseudo-Mersenne 2^64 - c, c < 2^32,
+                          6 double-precision FMA on 32-bit words (p >= 2^31, n <= 16384)  (3-6: sizes that live in LDS) */
 } cntt_plan_info_t;
 
 const char *cntt_last_error(void);      /* thread-local description of the last non-OK status */

@@ -77,6 +77,8 @@ def test_plans_match_oracle(oracle, bits, n, p):
         expect_cls = 3 if p < (1 << 50) else 4   # double-precision FMA butterflies (csrc/ntt_arith.hpp, CLS_FP / CLS_FP51)
     if bits == 64 and p >= (1 << 63) and (1 << 64) - p < (1 << 32) and n <= 16384:
         expect_cls = 5   # p = 2^64 - c, c < 2^32 (CLS_PM64)
+    if bits == 32 and p >= (1 << 31) and n <= 16384:
+        expect_cls = 6   # 32-bit words on double-precision butterflies (CLS_FPW)
     assert info.arith_class == expect_cls
 
 
