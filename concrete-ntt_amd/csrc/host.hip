@@ -250,12 +250,6 @@ template <class T> static int transform_class(const PrimePlan<T> *pl) {
     return (int)pl->mp.cls;
 }
 
-// class of the fused product / chain kernels: they have no CLS_FPW form (their pointwise steps work on 32-bit words)
-template <class T> static int fused_class(const PrimePlan<T> *pl) {
-    const int c = transform_class(pl);
-    return c == CLS_FPW ? (int)pl->mp.cls : c;
-}
-
 // per-device table replica, created on first use under the cache mutex
 template <class T> static int device_tables(const PrimePlan<T> *pl, DeviceTables<T> *out) {
     int dev = 0;
@@ -404,7 +398,7 @@ template <class T> static int mul_ntt_device(const PrimePlan<T> *pl, T *lhs, con
     if (batch >= ((size_t)1 << 32)) return fail(CNTT_EINVAL, "batch too large for one launch");
     DeviceTables<T> t;
     if (int rc = device_tables(pl, &t)) return rc;
-    const int tcls = fused_class(pl);
+    const int tcls = transform_class(pl);
     const hipError_t e = launch_mul_ntt<T>(pl->logn, tcls, lhs, rhs, alt_tables(tcls) ? t.fwd_fp : t.fwd,
                                            alt_tables(tcls) ? t.inv_fp : t.inv, pl->mp, (uint32_t)batch, st);
     if (e == hipSuccess) return CNTT_OK;
@@ -430,7 +424,7 @@ static int external_product_device(const PrimePlan<T> *pl, T *out, const T *term
     }
     DeviceTables<T> t;
     if (int rc = device_tables(pl, &t)) return rc;
-    const int tcls = fused_class(pl);
+    const int tcls = transform_class(pl);
     const hipError_t e = launch_ext_ntt<T>(pl->logn, tcls, out, terms, key, alt_tables(tcls) ? t.fwd_fp : t.fwd,
                                            alt_tables(tcls) ? t.inv_fp : t.inv, pl->mp, (uint32_t)batch, (uint32_t)nterms,
                                            (uint32_t)nout, accumulate, st);
@@ -1254,7 +1248,8 @@ static hipError_t product_fused2_try(const cntt_product *pl, bool inv, uint64_t 
                                      bool flag, hipStream_t st, int *rc_out) {
     if (pl->p32.size() != 2 || !pl->p64.empty() || batch == 0 || batch >= ((size_t)1 << 32)) return hipErrorNotSupported;
     const cntt_plan32 *q0 = pl->p32[0].get(), *q1 = pl->p32[1].get();
-    if (q0->mp.cls != q1->mp.cls) return hipErrorNotSupported;
+    const int cls = transform_class(q0);  // both primes above 2^31 (the reference's fast-path shape): CLS_FPW
+    if (cls != transform_class(q1)) return hipErrorNotSupported;
     ProductFusedTables F{};
     for (int i = 0; i < 2; ++i) {
         DeviceTables<uint32_t> t;
@@ -1262,11 +1257,11 @@ static hipError_t product_fused2_try(const cntt_product *pl, bool inv, uint64_t 
             *rc_out = rc;
             return hipErrorUnknown;
         }
-        F.twf[i] = t.fwd;
-        F.twi[i] = t.inv;
+        F.twf[i] = alt_tables(cls) ? t.fwd_fp : t.fwd;
+        F.twi[i] = alt_tables(cls) ? t.inv_fp : t.inv;
         F.P[i] = pl->p32[(size_t)i]->mp;
     }
-    return launch_product_fused2(q0->logn, (int)q0->mp.cls, inv, standard, res32, &F, pl->args, (uint32_t)batch, flag, st);
+    return launch_product_fused2(q0->logn, cls, inv, standard, res32, &F, pl->args, (uint32_t)batch, flag, st);
 }
 
 // Plan::fwd src/product.rs:273-357  (device pointers)

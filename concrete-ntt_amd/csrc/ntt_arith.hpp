@@ -479,7 +479,7 @@ template <> struct BoxOps<CLS_FPW> {
 template <> struct Bfly<uint32_t, CLS_FPW> {
     using T = uint32_t;
     static constexpr bool IS_FP = false;      // no in-transform range reductions (see above)
-    static constexpr bool FUSED_LAZY = false;
+    static constexpr bool FUSED_LAZY = true;  // the fused kernels' pointwise steps take the centred int32 pattern
     // canonical word -> centred residue as an int32 pattern
     static __device__ __forceinline__ T load_fix(T v, const ModParams<T> &P) { return v > (P.p >> 1) ? v - P.p : v; }
     static __device__ __forceinline__ T reduce(T v, const ModParams<T> &) { return v; }
@@ -638,6 +638,11 @@ template <class T, int CLS> __device__ __forceinline__ T mul_for_inv(T a, T b, c
         // a: the forward transform's lazy double (|a| < 2^53), b: a canonical word from memory; result |.| <= 0.875 p
         const double p = Fp::d(P.fp_p), pinv = Fp::d(P.fp_pinv);
         return Fp::u(Fp::mul_data(Fp::reduce(Fp::d(a), p, pinv), Fp::from_word(b), p, pinv));
+    } else if constexpr (CLS == CLS_FPW) {
+        // a: centred int32 pattern left by the forward transform, b: a canonical word from memory; result: centred pattern
+        const double p = Fp::d(P.fp_p), pinv = Fp::d(P.fp_pinv);
+        const double t = Fp::mul_data((double)(int32_t)a, (double)b, p, pinv);  // |t| <= (1/2 + 2^-20) p: reduce once more
+        return (T)(int32_t)Fp::reduce(t, p, pinv);
     } else if constexpr (CLS == CLS_GENERIC) {
         return mont_mul(a, b, P.p, P.pinv_neg);
     } else if constexpr (CLS == CLS_STRICT) {
@@ -674,6 +679,10 @@ template <class T, int CLS> __device__ __forceinline__ T mul_acc_cls(T acc, T a,
     } else if constexpr (is_fp_class(CLS)) {
         const double p = Fp::d(P.fp_p), pinv = Fp::d(P.fp_pinv);
         return Fp::u(__dadd_rn(Fp::d(acc), Fp::mul_data(Fp::d(a), Fp::from_word(b), p, pinv)));
+    } else if constexpr (CLS == CLS_FPW) {  // accumulator, a: centred int32 patterns; b: canonical word
+        const double p = Fp::d(P.fp_p), pinv = Fp::d(P.fp_pinv);
+        const double t = Fp::mul_data((double)(int32_t)a, (double)b, p, pinv);
+        return (T)(int32_t)Fp::reduce(__dadd_rn((double)(int32_t)acc, t), p, pinv);
     } else {
         return mul_acc<T>(acc, a, b, P, CLS == CLS_GENERIC);
     }

@@ -45,6 +45,7 @@ __global__ __launch_bounds__(BLK, 2) void product_fwd2_kernel(uint32_t *__restri
             } else {
                 a[j] = (uint32_t)barrett_rem(s, A.prime[i], A.barrett[i]);
             }
+            a[j] = Bfly<uint32_t, CLS>::load_fix(a[j], F.P[i]);  // canonical word -> the class's register form
         }
         Wf::template pass<0, false, false>(a, lds, tid, F.twf[i], nullptr, F.P[i]);
         if (sub < batch) Wf::B::template scatter<RML>(a, res32 + (size_t)i * plane + ((size_t)sub << LOGN), ebaseL, false);
@@ -73,6 +74,8 @@ __global__ __launch_bounds__(BLK, 2) void product_inv2_kernel(uint64_t *__restri
         uint32_t *rp = res32 + (size_t)i * plane + ((size_t)subc << LOGN);
         uint32_t a[E];
         Wi::B::template gather<RM0>(a, (const uint32_t *)rp, ebase0, false);
+#pragma unroll
+        for (int j = 0; j < E; ++j) a[j] = Bfly<uint32_t, CLS>::load_fix(a[j], F.P[i]);
         Wi::template pass<0, false, false>(a, lds, tid, F.twi[i], nullptr, F.P[i]);
         if (sub < batch) Wi::B::template scatter<RML>(a, rp, ebaseL, false);  // inv(ntt) stays in the ntt buffer: src/product.rs:368-373
         Wi::wsync();

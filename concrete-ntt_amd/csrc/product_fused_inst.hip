@@ -33,6 +33,7 @@ static hipError_t pf_logn(int logn, int cls, bool inv, uint64_t *standard, uint3
             switch (cls) {
             case CLS_LAZY: return pf_one<LOGN, CLS_LAZY>(inv, standard, res32, F, A, batch, flag, st);
             case CLS_STRICT: return pf_one<LOGN, CLS_STRICT>(inv, standard, res32, F, A, batch, flag, st);
+            case CLS_FPW: return pf_one<LOGN, CLS_FPW>(inv, standard, res32, F, A, batch, flag, st);
             default: return pf_one<LOGN, CLS_GENERIC>(inv, standard, res32, F, A, batch, flag, st);
             }
         }

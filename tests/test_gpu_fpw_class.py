@@ -98,9 +98,9 @@ def test_fpw_class_boundary(oracle):
 
 
 @pytest.mark.parametrize("n", [32, 256, 1024, 4096])
-def test_fpw_plan_fused_product_and_chain_still_exact(oracle, n):
-    """The fused product and the fused mul_accumulate chain of such a plan stay on the Montgomery class (their pointwise
-    steps work on 32-bit words): same values as the separate calls, whose transforms now run in CLS_FPW."""
+def test_fpw_fused_product_and_chain(oracle, n):
+    """The fused product and the fused mul_accumulate chain in CLS_FPW (pointwise steps on centred int32 patterns):
+    same values as the oracle and as the three separate calls; the first polynomial is the extreme one (every word p-1)."""
     plan, ref = prime32.Plan.try_new(n, P32), oracle.Plan.try_new(n, P32, 32)
     batch = 9
     a = oracle.fill_uniform(batch * n, P32, 51, 32)
@@ -120,9 +120,11 @@ def test_fpw_plan_fused_product_and_chain_still_exact(oracle, n):
     plan.mul_assign_normalize_batch(dc, to_dev(bn))
     plan.inv_batch(dc)
     assert np.array_equal(to_host(dc), want)
-    J, O = 3, 2
+    J, O = 11, 3
     terms = oracle.fill_uniform(batch * J * n, P32, 61, 32)
     key = oracle.fill_uniform(J * O * n, P32, 62, 32)
+    terms[: J * n] = P32 - 1
+    key[:n] = P32 - 1
     exp = np.zeros(batch * O * n, dtype=np.uint32)
     tn = terms.copy()
     ref.fwd_batch(tn, 4)
@@ -140,7 +142,8 @@ def test_fpw_plan_fused_product_and_chain_still_exact(oracle, n):
 
 def test_fpw_equals_montgomery_butterflies_on_a_large_batch():
     """The same plan with CNTT_DISABLE_FP=1 (Montgomery class) in a child process: identical bytes for fwd and inv on 8192
-    random polynomials of N = 1024 and 512 of N = 16384 -- a device-vs-device check of two independent arithmetic paths."""
+    random polynomials of N = 1024 (plus the fused product and a fused chain) and 512 of N = 16384 -- a device-vs-device
+    check of two independent arithmetic paths."""
     code = r'''
 import hashlib
 import torch
@@ -155,6 +158,12 @@ for n, batch in ((1024, 8192), (16384, 512)):
     out.append(plan.info().arith_class)
     x = a.clone(); plan.fwd_batch(x); out.append(hashlib.sha256(x.cpu().numpy().tobytes()).hexdigest())
     x = a.clone(); plan.inv_batch(x); out.append(hashlib.sha256(x.cpu().numpy().tobytes()).hexdigest())
+    if n == 1024:
+        b = torch.empty_like(a); cntt.fill_uniform(b, p, 6)
+        x = a.clone(); plan.mul_ntt_batch(x, b); out.append(hashlib.sha256(x.cpu().numpy().tobytes()).hexdigest())
+        o = torch.zeros(64 * 2 * n, dtype=torch.int32, device="cuda")
+        plan.external_product_batch(o, a[: 64 * 5 * n], b[: 5 * 2 * n], 5, 2)
+        out.append(hashlib.sha256(o.cpu().numpy().tobytes()).hexdigest())
 print(*out)
 ''' % P32
     res = []
@@ -163,5 +172,6 @@ print(*out)
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         res.append(r.stdout.split())
-    assert res[0][0] == "6" and res[0][3] == "6" and res[1][0] == "2" and res[1][3] == "2"
-    assert [res[0][i] for i in (1, 2, 4, 5)] == [res[1][i] for i in (1, 2, 4, 5)]
+    # per size: class, sha(fwd), sha(inv); N = 1024 also sha(fused product), sha(fused chain)
+    assert res[0][0] == "6" and res[0][5] == "6" and res[1][0] == "2" and res[1][5] == "2"
+    assert len(res[0]) == 8 and [x for i, x in enumerate(res[0]) if i not in (0, 5)] == [x for i, x in enumerate(res[1]) if i not in (0, 5)]

@@ -21,7 +21,7 @@ template <class T, int CLS, bool INV, int NB> __global__ void k(T *o, const T *i
     const uint32_t t = threadIdx.x;
 #if %(BOX)s
     // the form the kernels use for 32-bit lazy residues: values held in 64-bit "boxes" (BoxOps, ntt_arith.hpp)
-    uint64_t x = box32(in[t]), y = box32(in[t + 256]);
+    uint64_t x = BoxOps<CLS>::box(in[t], P), y = BoxOps<CLS>::box(in[t + 256], P);
 #else
     T x = in[t], y = in[t + 256];
 #endif
@@ -39,7 +39,11 @@ template <class T, int CLS, bool INV, int NB> __global__ void k(T *o, const T *i
 #endif
         auto s = x; x = y; y = s;   // alternate the roles so that both outputs stay live
     }
+#if %(BOX)s
+    o[t] = BoxOps<CLS>::unbox(x, P); o[t + 256] = BoxOps<CLS>::unbox(y, P);
+#else
     o[t] = (T)x; o[t + 256] = (T)y;
+#endif
 }
 template __global__ void k<%(T)s, %(CLS)s, %(INV)s, 4>(%(T)s *, const %(T)s *, const TwPair<%(T)s> *, ModParams<%(T)s>);
 template __global__ void k<%(T)s, %(CLS)s, %(INV)s, 12>(%(T)s *, const %(T)s *, const TwPair<%(T)s> *, ModParams<%(T)s>);
@@ -84,7 +88,8 @@ CASES = [("uint64_t", "CLS_LAZY", "u64 lazy (p < 2^62): Harvey butterfly, Shoup 
          ("uint64_t", "CLS_FP51", "u64 p < 2^51 (double-precision FMA; reductions every 3rd fwd stage / every inv stage not included)"),
          ("uint32_t", "CLS_LAZY", "u32 lazy (p < 2^30), plain 32-bit registers (not used by the kernels)"),
          ("uint32_t", "CLS_LAZY", "u32 lazy (p < 2^30), boxed: x + y w - q p as two v_mad_u64_u32 on 64-bit boxes (what the kernels run)", True),
-         ("uint32_t", "CLS_GENERIC", "u32 generic (Montgomery)")]
+         ("uint32_t", "CLS_GENERIC", "u32 generic (Montgomery): p >= 2^31 beyond the LDS-resident sizes"),
+         ("uint32_t", "CLS_FPW", "u32 p >= 2^31 on doubles in 64-bit boxes (CLS_FPW; per pass boundary and element: +1 to box, +4 to unbox)", True)]
 
 if __name__ == "__main__":
     print(__doc__.split("\n\n")[0])
