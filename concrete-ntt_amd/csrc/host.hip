@@ -959,7 +959,10 @@ static size_t native_park_bytes(const cntt_native *pl, size_t batch) {
 }
 static size_t native_workspace_bytes(const cntt_native *pl, size_t batch) {
     const size_t park = native_park_bytes(pl, batch);
-    return park ? park : 2 * (size_t)pl->info.nprimes * batch * pl->n * pl->rbytes();
+    if (park) return park;
+    // the LDS-parked whole-product kernel (32 <= n <= 4096, every fused kind but native128) needs no workspace at all
+    if (native_fusable(pl, batch) && pl->p32[0]->logn >= 5 && pl->p32[0]->logn <= 12) return 0;
+    return 2 * (size_t)pl->info.nprimes * batch * pl->n * pl->rbytes();
 }
 // caller holds pl->cache->mu
 static int native_workspace(const cntt_native *pl, size_t need, Workspace **out) {
