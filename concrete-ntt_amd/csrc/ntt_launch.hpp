@@ -86,8 +86,8 @@ inline int device_num_cus() {
 inline bool native_fused_persistent(int kind, int logn) { return logn == 13 || logn == 14 || (kind == 2 && logn >= 5 && logn <= 12); }
 // words of one residue tile of a workgroup (256 threads x 16 coefficients hold 4096 / n products below n = 4096)
 inline size_t native_fused_tile_words(int logn) { return logn < 12 ? (size_t)4096 : (size_t)1 << logn; }
-// workgroups of the persistent kernel: what is resident on `ncu` compute units (two per unit; one 1024-thread workgroup at
-// n = 16384), at most one per group of products
+// workgroups of the persistent kernel: what is resident on `ncu` compute units (four 256-thread workgroups per unit for
+// native128 below n = 8192, two 512-thread ones at n = 8192, one 1024-thread one at n = 16384), at most one per group of products
 inline uint32_t native_fused_grid(int logn, int ncu, uint32_t batch) {
     const size_t ppb = native_fused_tile_words(logn) >> logn;
     const size_t groups = ((size_t)batch + ppb - 1) / ppb, g = (size_t)ncu * (logn == 14 ? 1u : logn == 13 ? 2u : 4u);
