@@ -39,4 +39,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except BrokenPipeError:  # `| head`
+        sys.exit(0)
