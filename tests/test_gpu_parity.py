@@ -657,6 +657,40 @@ def test_batch_calls_capture_into_a_hip_graph(oracle):
     assert np.array_equal(ref_native[:n], prod0)
 
 
+@pytest.mark.parametrize("kind,n", [("native64_plan32", 8192), ("native128_plan32", 1024), ("native64_plan52", 512)])
+def test_native_polymul_with_workspace_captures_into_a_hip_graph(oracle, kind, n):
+    """The native plans that need a workspace (parking area of the persistent kernel, residue arrays of the composed
+    pipeline): after cntt_native_reserve the call neither allocates nor synchronises, so it captures; replays on fresh
+    inputs are checked against the oracle."""
+    torch = _torch()
+    cls = NATIVE[kind]
+    plan, ref = cls.try_new(n), oracle.Native(kind, n)
+    batch = 5
+    wpp = n * (2 if ref.word == 16 else 1)
+    ins = [_native_inputs(oracle, kind, n, 41000 + b, cls.BINARY) for b in range(2 * batch)]
+    plan.reserve(batch)
+    dl = to_dev(np.concatenate([ins[b][1] for b in range(batch)]))
+    dr = to_dev(np.concatenate([ins[b][2] for b in range(batch)]))
+    dp = torch.zeros_like(dl)
+    plan.negacyclic_polymul_batch(dp, dl, dr)   # warm-up: table uploads happen outside the capture
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        plan.negacyclic_polymul_batch(dp, dl, dr)
+    for rnd in range(2):
+        lhs = np.concatenate([ins[rnd * batch + b][1] for b in range(batch)])
+        rhs = np.concatenate([ins[rnd * batch + b][2] for b in range(batch)])
+        dl.copy_(to_dev(lhs))
+        dr.copy_(to_dev(rhs))
+        dp.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        want = np.zeros_like(lhs)
+        ref.negacyclic_polymul_batch(want, lhs, rhs, batch, 2)
+        assert np.array_equal(to_host(dp, lhs.dtype), want), (kind, n, rnd)
+    assert wpp * batch == dl.numel()
+
+
 @pytest.mark.parametrize("bits,logn,p", [
     (64, 17, 4611686018425815041),      # lazy class, depth-3 global stages (62-bit prime = 1 mod 2^18)
     (64, 18, 18446744069414584321),     # Solinas (generic class), depth 4
