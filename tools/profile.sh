@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/${1:-prof}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="$R/bench.py --gpus 1 --steps 20 --warmup 5"
+ARGS="$R/bench.py --gpus 1 --steps 200 --warmup 5"
 ZOO="$R/tools/prof_workload.py 4"
 echo "== kernel trace" | tee -a $R/gpurun_out/progress.log
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1; echo "trace rc=$?" | tee -a $R/gpurun_out/progress.log
