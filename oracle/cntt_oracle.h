@@ -13,6 +13,11 @@
  *       independent pure-Python big-int restatement, and
  *   (3) the reference's own property suite (README.md:41-57,
  *       src/prime64.rs:1211-1267, src/native64.rs:1176-1243, ...).
+ * What that pins and what it does not: everything the reference's tests state as literals or
+ * properties (prime search answers, inv(fwd(x)) = n x, products equal to the schoolbook wrapping
+ * convolution, CRT round trips) is pinned.  The raw NTT-DOMAIN words (the bytes fwd() leaves) are
+ * PARITY UNPINNED against the reference itself: it holds no such vectors and cannot be run here;
+ * they are fixed only by the agreement of the independent restatements (1) and (2).
  *
  * Every function cites the reference file:line it follows (paths relative to
  * /root/reference/).
