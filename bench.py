@@ -202,18 +202,22 @@ class Timer:
         return e0.elapsed_time(e1) / reps
 
 
-def pmc_traffic(kernel_key, batch):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes of THIS build (profiles/pmc_traffic.json, written
-    by tools/profile.sh: FETCH_SIZE doubled for gfx950 + WRITE_SIZE, MI355X_MICROARCH.md section HBM).  The passes run
-    the kernel at the bench's own shape (batch 65536); None for any other batch or when no profile is committed."""
+def pmc_traffic(kernel_key, batch, lib_hash):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json, written by
+    tools/profile.sh: FETCH_SIZE doubled for gfx950 + WRITE_SIZE, MI355X_MICROARCH.md section HBM).  The passes run the
+    kernel at the bench's own shape (batch 65536); None for any other batch or when no profile is committed.  The file is
+    stamped with the source hash of the library it was measured on (`csrc_hash`); the third value returned is True when
+    that stamp is missing or differs from the hash compiled into the library that is loaded now (stale profile)."""
     if batch != 65536:
-        return None, None
+        return None, None, None
     try:
         with open(PMC_FILE) as f:
-            e = json.load(f)[kernel_key]
-        return float(e["hbm_bytes_per_launch"]), "profiles/pmc_traffic.json: " + e.get("source", "rocprofv3 --pmc")
+            doc = json.load(f)
+        e = doc[kernel_key]
+        stale = not lib_hash or doc.get("csrc_hash") != lib_hash
+        return float(e["hbm_bytes_per_launch"]), "profiles/pmc_traffic.json: " + e.get("source", "rocprofv3 --pmc"), stale
     except (OSError, KeyError, ValueError, TypeError):
-        return None, None
+        return None, None, None
 
 
 def extra_configs(args, torch, cntt, timer, rank, world, dist, dev):
@@ -356,6 +360,14 @@ def run_rank(args):
     if args.dry_run:
         return dry_run(args, world, rank)
 
+    # This command's stdout carries exactly ONE line (rank 0's JSON).  RCCL prints a version banner on the C-level
+    # stdout when the first communicator comes up, gloo announces its connections, and under torch.distributed.run
+    # every rank shares the launcher's stdout: from here on fd 1 is stderr for the whole process; the line goes to the
+    # saved descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import concrete_ntt_amd as cntt
     from concrete_ntt_amd import prime64
@@ -370,7 +382,7 @@ def run_rank(args):
                          % (rank, local_rank, ndev))
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.dist_backend == "nccl":
@@ -429,6 +441,10 @@ def run_rank(args):
         step_unfused()
     fence()
     unfused = time.perf_counter() - t1
+    if dist is not None:
+        t = torch.tensor([unfused], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        unfused = float(t.item())
 
     # per-kernel timing with HIP events on the launch stream (roofline leg), after the timed region
     reps = 50
@@ -437,14 +453,16 @@ def run_rank(args):
     inv_ms = timer.ms(lambda: plan.inv_batch(a), reps)
     mul_ms = timer.ms(lambda: plan.mul_assign_normalize_batch(a, b), reps)
     alg_bytes = 2 * N * 8 * batch                     # 2*N*sizeof(T) = 16384 B per transform
-    # Dominant kernel of the timed region = the fused step kernel: 2 transforms per polynomial per launch.
-    # roofline.achieved = per-transform algorithmic bytes x transforms per launch / launch time (the task's
-    # definition).  The kernel itself moves only 3*N*8 bytes per polynomial -- read lhs, read rhs_ntt, write lhs --
-    # which is `moved_bytes_*` (the real HBM rate) and what `traffic` reports from the rocprofv3 PMC passes.
-    fused_alg = 2 * alg_bytes
-    achieved = fused_alg / (fused_ms * 1e-3) / 1e9
+    # Dominant kernel of the timed region = the fused step kernel (2 transforms per polynomial per launch).  It moves
+    # 3*N*8 bytes per polynomial -- read lhs, read rhs_ntt, write lhs -- and THAT is what roofline.achieved / frac are
+    # computed from (the rocprofv3 PMC passes measure the same figure: `traffic`).  The per-transform accounting of
+    # SURVEY 8(d) (2 x 16384 B per polynomial for a kernel that moves 24576 B) is kept as `per_transform_frac`, and the
+    # stand-alone fwd / inv kernels -- where moved = algorithmic -- as fwd_frac / inv_frac.
     moved = 3 * N * 8 * batch
-    traffic, traffic_src = pmc_traffic("mul_kernel_wp<u64, 10, 0, 768, 3>", batch)
+    lib_hash = cntt.build_info().get("csrc_hash")
+    traffic, traffic_src, traffic_stale = pmc_traffic("mul_kernel_wp<u64, 10, 0, 768, 3>", batch, lib_hash)
+    achieved = moved / (fused_ms * 1e-3) / 1e9
+    per_transform = 2 * alg_bytes / (fused_ms * 1e-3) / 1e9
 
     extras = []
     try:
@@ -468,19 +486,23 @@ def run_rank(args):
                        "sharding": "independent batch shards, no collective",
                        "launcher": "torchrun" if os.environ.get("TORCHELASTIC_RUN_ID") else
                                    ("bench.py --gpus" if world > 1 else "single process"),
-                       "dist_backend": args.dist_backend if world > 1 else None},
+                       "dist_backend": args.dist_backend if dist is not None else None,
+                       "rccl_ranks": world if (dist is not None and args.dist_backend == "nccl") else 0},
             "per_gpu_value": units / elapsed / world,
             "unfused_value": units / unfused, "unfused_ms_per_step": 1e3 * unfused / args.steps,
-            "roofline": {"bound": "hbm", "kernel": "mul_kernel_wp<u64, LOGN=10, lazy> (fwd + pointwise + inv fused)",
+            "fwd_inv_standalone_value": world * 2 * batch / ((fwd_ms + inv_ms) * 1e-3),   # API-faithful fwd + inv launches, NTT/s
+            "roofline": {"bound": "valu/power", "priced_against": "hbm",
+                         "kernel": "mul_kernel_wp<u64, LOGN=10, lazy> (fwd + pointwise + inv fused)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "limiter": "VALU issue of the 62-bit Shoup butterflies under the package power cap (DESIGN.md 5); "
-                                    "HBM is the stated roofline",
-                         "algorithmic_bytes_per_launch": fused_alg, "avg_launch_ms": fused_ms,
+                         "traffic_stale": traffic_stale, "csrc_hash": lib_hash,
+                         "limiter": "VALU issue of the 62-bit Shoup butterflies under the package power cap (DESIGN.md 5): "
+                                    "achieved / peak are HBM bytes actually moved against the 8 TB/s HBM roofline",
+                         "moved_bytes_per_launch": moved, "avg_launch_ms": fused_ms,
                          "transforms_per_launch": 2 * batch,
-                         "moved_bytes_per_launch": moved,
-                         "moved_bytes_achieved": moved / (fused_ms * 1e-3) / 1e9,
-                         "moved_bytes_frac": moved / (fused_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "per_transform_bytes_per_launch": 2 * alg_bytes,
+                         "per_transform_achieved": per_transform,
+                         "per_transform_frac": per_transform / HBM_PEAK_GBS,
                          "fwd_kernel_ms": fwd_ms, "fwd_frac": alg_bytes / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "inv_kernel_ms": inv_ms, "inv_frac": alg_bytes / (inv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "pointwise_kernel_ms": mul_ms,
@@ -493,7 +515,9 @@ def run_rank(args):
             except Exception as e:  # the baseline is a reported extra, never a reason to lose the bench line
                 out["cpu_baseline"] = {"value": None, "unit": "NTT/s", "cores": 0, "kind": "port",
                                        "sample": "failed: %r" % (e,)}
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    os.close(json_fd)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -512,6 +536,9 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL, one rank per GPU) is what the driver uses; gloo lets several ranks share one "
                          "GPU to rehearse the multi-process path on a 1-GPU box")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the process group even with one rank (a 1-rank RCCL rehearsal of the multi-GPU legs; "
+                         "needs RANK / WORLD_SIZE / MASTER_* in the environment, e.g. torch.distributed.run)")
     ap.add_argument("--ramp-seconds", type=float, default=2.0,
                     help="untimed back-to-back steps before the W warm-up steps, so that the timed region "
                          "runs at the steady-state DVFS clock instead of inside the ramp from idle")

@@ -19,6 +19,12 @@ def version():
     return lib().cntt_version().decode()
 
 
+def build_info():
+    """{'version': ..., 'csrc_hash': ...}: the hash of the csrc/ sources the loaded library was built from."""
+    v = version()
+    return {"version": v, "csrc_hash": v.split("csrc:")[1].strip() if "csrc:" in v else None}
+
+
 def fill_uniform(tensor, bound, seed):
     """Synthetic input generated on the device into a 4- or 8-byte-element tensor."""
     ptr, count, esz, where, stream = _lib.buffer_info(tensor)

@@ -122,9 +122,39 @@ def default_swz(bits, logn, loge, passes):
     return terms
 
 
+# FAM 2 ("wave blocks", 64-bit words, N = 4096 ... 16384): the top LOGN-10 stages run in ONE pass on registers whose
+# twiddles are all wave-uniform, then the polynomial crosses LDS once (the only exchange that needs a workgroup barrier)
+# and every wavefront owns a contiguous 1024-point block on which it runs the N = 1024 schedule with wave-private
+# exchanges.  The inverse is the mirror image.
+BLK_LOGN = 10
+BLK_PASSES = [(0x381, 0x380), (0x78, 0x78), (0x207, 0x7)]   # the (64, 10) forward schedule
+BLK_SWZ = [(3, 3, 1), (6, 7, 2)]                            # and its swizzle (acts inside a 1024-word block)
+
+
+def fam2_supported(bits, logn):
+    return bits == 64 and 12 <= logn <= 14
+
+
+def make_sched_fam2(bits, logn, inv):
+    assert fam2_supported(bits, logn)
+    top = logn - BLK_LOGN                       # stages of the first pass
+    gm0 = ((1 << top) - 1) << BLK_LOGN
+    # the other 4 - top register bits: bit 0 (16-byte accesses), then the bits just below the block boundary
+    extra = [0, 9][:4 - top]
+    rm0 = gm0 | sum(1 << b for b in extra)
+    passes = [(rm0, gm0)] + BLK_PASSES
+    if inv:
+        passes = passes[::-1]
+    tpp = 1 << (logn - 4)
+    return Sched(bits, logn, inv, 4, passes, list(BLK_SWZ), tpp)
+
+
 def make_sched(bits, logn, inv, fam=0):
     """fam 0: the tuned schedule; fam 1: the 16-coefficients-per-thread schedule where fam 0 overrides LOGE
-    (the whole-polymul kernels keep K residue tiles in registers and cannot afford 32 per thread)."""
+    (the whole-polymul kernels keep K residue tiles in registers and cannot afford 32 per thread);
+    fam 2: wave blocks (make_sched_fam2)."""
+    if fam == 2:
+        return make_sched_fam2(bits, logn, inv)
     ov = OVERRIDES.get((bits, logn, inv), {})
     if fam == 1:
         ov = {k: v for k, v in ov.items() if k != "loge"}
@@ -283,13 +313,15 @@ def emit(path):
                 keys.append((bits, logn, inv, 0))
                 if "loge" in OVERRIDES.get((bits, logn, inv), {}):
                     keys.append((bits, logn, inv, 1))
+                if fam2_supported(bits, logn):
+                    keys.append((bits, logn, inv, 2))
     for bits, logn, inv, fam in keys:
             if True:
                 s = make_sched(bits, logn, inv, fam)
                 np_ = len(s.passes)
                 swz = list(s.swz) + [(0, 0, 0)] * (2 - len(s.swz))
                 lines.append("template <> struct Sched<%d, %d, %s%s> {" % (bits, logn, "true" if inv else "false",
-                                                                         ", 1" if fam else ""))
+                                                                         ", %d" % fam if fam else ""))
                 lines.append("    static constexpr int LOGE = %d, NPASS = %d, BLOCK = %d;" % (s.loge, np_, s.block))
                 lines.append("    static constexpr uint32_t RMASK[%d] = {%s};" %
                              (np_, ", ".join("0x%xu" % r for r, _ in s.passes)))
@@ -316,8 +348,10 @@ def check():
                 pass
             pl = gg.Plan(n, p, bits)
             a = [rnd.randrange(p) for _ in range(n)]
-            for inv, fam in ((False, 0), (True, 0), (False, 1), (True, 1)):
+            for inv, fam in ((False, 0), (True, 0), (False, 1), (True, 1), (False, 2), (True, 2)):
                 if fam == 1 and "loge" not in OVERRIDES.get((bits, logn, inv), {}):
+                    continue
+                if fam == 2 and not fam2_supported(bits, logn):
                     continue
                 s = make_sched(bits, logn, inv, fam)
                 table = pl.inv_twid if inv else pl.twid

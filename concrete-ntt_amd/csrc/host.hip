@@ -46,7 +46,8 @@ static int fail(int code, const char *fmt, ...) {
     } while (0)
 
 extern "C" const char *cntt_last_error(void) { return g_err.c_str(); }
-extern "C" const char *cntt_version(void) { return "cntt-hip 0.1 (gfx950)"; }
+#include "build_hash.inc"  // CNTT_CSRC_HASH: sha256 of the csrc/ sources this library was built from (Makefile)
+extern "C" const char *cntt_version(void) { return "cntt-hip 0.3 (gfx950) csrc:" CNTT_CSRC_HASH; }
 extern "C" int cntt_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -278,11 +279,19 @@ template <class T> static int device_tables(const PrimePlan<T> *pl, DeviceTables
         }
     }
     DeviceTables<T> t;
-    HIP_TRY(hipMalloc((void **)&t.fwd, n * sizeof(TwPair<T>)));
-    if (hipMalloc((void **)&t.inv, n * sizeof(TwPair<T>)) != hipSuccess) {
-        (void)hipFree(t.fwd);
+    // every early return below (allocation or upload failure) releases what this call allocated so far
+    struct Release {
+        DeviceTables<T> *t;
+        ~Release() {
+            if (!t) return;
+            (void)hipFree(t->fwd);
+            (void)hipFree(t->inv);
+            (void)hipFree(t->fwd_fp);
+            (void)hipFree(t->inv_fp);
+        }
+    } release{&t};
+    if (hipMalloc((void **)&t.fwd, n * sizeof(TwPair<T>)) != hipSuccess || hipMalloc((void **)&t.inv, n * sizeof(TwPair<T>)) != hipSuccess)
         return fail(CNTT_ENOMEM, "hipMalloc of the twiddle tables failed");
-    }
     HIP_TRY(hipMemcpy(t.fwd, f.data(), n * sizeof(TwPair<T>), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(t.inv, i.data(), n * sizeof(TwPair<T>), hipMemcpyHostToDevice));
     if (pl->mp.fp || pl->mp.pm_c) {
@@ -312,15 +321,12 @@ template <class T> static int device_tables(const PrimePlan<T> *pl, DeviceTables
             }
         }
         if (hipMalloc((void **)&t.fwd_fp, n * sizeof(TwPair<T>)) != hipSuccess ||
-            hipMalloc((void **)&t.inv_fp, n * sizeof(TwPair<T>)) != hipSuccess) {
-            (void)hipFree(t.fwd);
-            (void)hipFree(t.inv);
-            (void)hipFree(t.fwd_fp);
+            hipMalloc((void **)&t.inv_fp, n * sizeof(TwPair<T>)) != hipSuccess)
             return fail(CNTT_ENOMEM, "hipMalloc of the twiddle tables failed");
-        }
         HIP_TRY(hipMemcpy(t.fwd_fp, f.data(), n * sizeof(TwPair<T>), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(t.inv_fp, i.data(), n * sizeof(TwPair<T>), hipMemcpyHostToDevice));
     }
+    release.t = nullptr;  // the cache owns the tables from here
     pl->cache->per_device[dev] = t;
     *out = t;
     return CNTT_OK;

@@ -1,0 +1,391 @@
+// "Wave block" transforms for 64-bit words, N = 4096 ... 16384 (schedule family 2 of gen_sched.py).
+//
+// Replaces the same reference engines as ntt_kernel.hpp (fwd: src/prime64/shoup.rs:544-706, inv: :1306-1468) with the
+// same stage / twiddle indexing; what changes is who owns what.  A polynomial of N = 2^LOGN words belongs to one
+// workgroup of N/16 threads and crosses LDS between wavefronts exactly ONCE:
+//   forward   pass 0: the top LOGN-10 stages on registers loaded straight from HBM at a stride of N/16 words
+//                     (consecutive lanes on consecutive words; every twiddle of these stages is workgroup-uniform);
+//             LDS transpose -- the one exchange between wavefronts (workgroup barrier);
+//             passes 1-3: every wavefront owns a contiguous 1024-word block and runs the N = 1024 schedule on it
+//                     (3 + 4 + 3 stages, exchanges through the wavefront's own 8 KiB of the buffer: no barrier; the
+//                     first of them has wave-uniform twiddles: scalar loads), then stores its block coalesced.
+//   inverse   the mirror image: block passes first, one transpose, the top stages last.
+// A second barrier per polynomial only keeps the next polynomial's first LDS write behind everybody's last read of the
+// current one; a whole pass of butterflies lies between the two, so nobody waits at it for long.
+// (The round-2 walk of these sizes -- NttWp with one polynomial per workgroup, removed in round 3 -- crossed 9-11
+// workgroup barriers per polynomial with three cross-wave exchanges and two cross-wave I/O transposes, and its compiler-
+// placed vmcnt waits retired every prefetch right after issue: profiles/r03_blk_vs_round2.txt.)
+#pragma once
+#include "ntt_kernel.hpp"
+
+// Timing-only ablations for tools/blk_lab.hip (results are wrong with any bit set; the library never defines it):
+//   1: no workgroup barriers   2: every twiddle from table entry 1 (no thread-dependent loads)   4: no prefetch
+//   8: no LDS exchanges   16: no HBM loads / stores   32: no HBM stores (loads kept)   64: every load from the first 256 polynomials (cache-resident)
+#ifndef CNTT_BLK_LAB
+#define CNTT_BLK_LAB 0
+#endif
+// phase stamps of the timing lab (tools/blk_lab.hip defines it; nothing in the library)
+#ifndef CNTT_BLK_STAMP
+#define CNTT_BLK_STAMP(k)
+#endif
+
+namespace cntt {
+
+template <class T, int LOGN, bool INV, int CLS, int TWC = 2>
+struct NttBlk {
+    using B = NttKernel<T, LOGN, INV, CLS, false, 2>;
+    using S = typename B::S;
+    static_assert(sizeof(T) == 8 && B::NPASS == 4 && B::LOGE == 4, "wave-block schedules: 64-bit words, four passes of 16");
+    static constexpr int E = B::E, TPP = B::TPP, WPB = B::TPP;
+    static constexpr uint32_t FULL = B::FULL;
+    static constexpr uint32_t BLK_IO = 0x381u;  // a wavefront's block, 16 bytes per lane on consecutive addresses
+    static constexpr uint32_t RM0 = S::RMASK[0], RM1 = S::RMASK[1], RM2 = S::RMASK[2], RM3 = S::RMASK[3];
+#ifdef CNTT_BLK_DIRECT_IO   // lab: HBM accessed in the block pass's own register layout (64 B per lane), no LDS transpose
+    static constexpr uint32_t LOAD_RM = RM0;
+    static constexpr uint32_t STORE_RM = RM3;
+#else
+    static constexpr uint32_t LOAD_RM = INV ? BLK_IO : RM0;   // HBM layouts: the top pass reads / writes its own layout
+    static constexpr uint32_t STORE_RM = INV ? RM3 : BLK_IO;
+#endif
+    static constexpr int HARD = INV ? 2 : 0;                  // the exchange after this pass crosses wavefronts
+    static_assert(((INV ? RM0 : RM3) & ~0x3ffu) == 0 && ((INV ? RM3 : RM0) >> 10) == (FULL >> 10), "block passes / top pass");
+
+    template <uint32_t RM> static constexpr int nv() { return B::template vec_elems<RM>(); }
+
+    template <bool PRIV> static __device__ __forceinline__ void xsync() {
+        if constexpr (PRIV) {  // LDS operations of one wavefront execute in order: only the compiler must not reorder
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("" ::: "memory");
+        } else {  // raw barrier behind an LDS-only wait: __syncthreads() would drain the prefetched global loads too
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if constexpr (!(CNTT_BLK_LAB & 1)) __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+    }
+
+    // ---- asynchronous prefetch of the next polynomial (see NttKernel::gather_async): 16- or 8-byte loads ----
+    using Vec4 = __attribute__((ext_vector_type(4))) uint32_t;
+    using Vec2 = __attribute__((ext_vector_type(2))) uint32_t;
+    template <uint32_t RM> struct Pf {
+        static constexpr int NV = nv<RM>(), NVEC = E / NV;
+        using V = typename std::conditional<NV == 2, Vec4, Vec2>::type;
+        template <int JV = 0> static __device__ __forceinline__ void issue(V (&v)[NVEC], const T *tile, uint32_t voff) {
+            if constexpr (JV < NVEC) {
+                constexpr uint32_t BYTE = cdep((uint32_t)(JV * NV), RM) * (uint32_t)sizeof(T);
+                constexpr uint32_t WIN = BYTE & ~4095u, IMM = BYTE & 4095u;
+                const char *base = reinterpret_cast<const char *>(tile) + WIN;
+#ifdef CNTT_BLK_NT
+                if constexpr (NV == 2)
+                    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3 nt" : "=v"(v[JV]) : "v"(voff), "s"(base), "n"(IMM) : "memory");
+                else
+                    asm volatile("global_load_dwordx2 %0, %1, %2 offset:%3 nt" : "=v"(v[JV]) : "v"(voff), "s"(base), "n"(IMM) : "memory");
+#else
+                if constexpr (NV == 2)
+                    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(v[JV]) : "v"(voff), "s"(base), "n"(IMM) : "memory");
+                else
+                    asm volatile("global_load_dwordx2 %0, %1, %2 offset:%3" : "=v"(v[JV]) : "v"(voff), "s"(base), "n"(IMM) : "memory");
+#endif
+                issue<JV + 1>(v, tile, voff);
+            }
+        }
+        // every destination vector is a tied operand of the ONE waiting statement
+        template <int YOUNGER> static __device__ __forceinline__ void wait(V (&v)[NVEC]) {
+            if constexpr (NVEC == 8) {
+                asm volatile("s_waitcnt vmcnt(%8)"
+                             : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])
+                             : "n"(YOUNGER)
+                             : "memory");
+            } else {
+                static_assert(NVEC == 16, "16 coefficients per thread");
+                asm volatile("s_waitcnt vmcnt(%16)"
+                             : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
+                               "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15])
+                             : "n"(YOUNGER)
+                             : "memory");
+            }
+        }
+        static __device__ __forceinline__ void unpack(T (&r)[E], const V (&v)[NVEC]) {
+#pragma unroll
+            for (int j = 0; j < E; j += NV) {
+                r[j] = (T)v[j / NV][0] | ((T)v[j / NV][1] << 32);
+                if constexpr (NV == 2) r[j + 1] = (T)v[j / NV][2] | ((T)v[j / NV][3] << 32);
+            }
+        }
+    };
+
+    template <int K, bool NORM>
+    static __device__ __forceinline__ void stages(T (&r)[E], uint32_t tidv, const TwPair<T> *__restrict__ tw, const ModParams<T> &P) {
+        constexpr uint32_t CM = FULL & ~S::RMASK[K];
+        if constexpr (CNTT_BLK_LAB & 2) {
+            B::template stages<K, 0, false, NORM, TWC>(r, 0u, 0u, 0u, tw, P, tidv, nullptr);
+            return;
+        }
+        B::template stages<K, 0, false, NORM, TWC>(r, pdep<CM>(tidv), 0u, 0u, tw, P, tidv, nullptr);
+    }
+    // exchange between pass K and pass K + 1
+    template <int K, bool PRE_PRIV> static __device__ __forceinline__ void exch(T (&r)[E], T *lds, uint32_t tidv) {
+        constexpr uint32_t RA = S::RMASK[K], RB = S::RMASK[K + 1];
+        xsync<PRE_PRIV>();  // what the buffer held has been read
+        if constexpr (!(CNTT_BLK_LAB & 8)) B::template scatter<RA>(r, lds, pdep<FULL & ~RA>(tidv), true);
+        xsync<K != HARD>();
+        if constexpr (!(CNTT_BLK_LAB & 8)) B::template gather<RB>(r, (const T *)lds, pdep<FULL & ~RB>(tidv), true);
+    }
+
+    // NORM: the last inverse stage also applies 1/N (fused products).
+    // HOOK: called where the scalar-twiddle part of the transform begins -- at the start of the forward transform, before
+    // the third pass of the inverse.  That is where a kernel issues its asynchronous prefetch: vmcnt retires in order, so
+    // the first wait for a thread-dependent twiddle load behind the prefetch would also wait for the prefetch; issued
+    // here it stays in flight across two passes of butterflies (and is live in registers only that long).
+    struct NoHook {
+        __device__ __forceinline__ void operator()() const {}
+    };
+    template <bool NORM = false, class HOOK = NoHook>
+    static __device__ __forceinline__ void transform(T (&r)[E], T *lds, uint32_t tidv, const TwPair<T> *__restrict__ tw,
+                                                     const ModParams<T> &P, const HOOK &hook = HOOK{}) {
+        if constexpr (!INV) {
+            hook();
+            CNTT_BLK_STAMP(8);
+            stages<0, false>(r, tidv, tw, P);
+            CNTT_BLK_STAMP(1);
+            exch<0, false>(r, lds, tidv);  // behind everybody's last read of the previous polynomial; then the one barrier
+            CNTT_BLK_STAMP(2);
+            stages<1, false>(r, tidv, tw, P);
+            CNTT_BLK_STAMP(3);
+            exch<1, true>(r, lds, tidv);
+            stages<2, false>(r, tidv, tw, P);
+            CNTT_BLK_STAMP(4);
+            exch<2, true>(r, lds, tidv);
+            stages<3, false>(r, tidv, tw, P);
+            CNTT_BLK_STAMP(5);
+        } else {
+            stages<0, false>(r, tidv, tw, P);
+            exch<0, true>(r, lds, tidv);
+            stages<1, false>(r, tidv, tw, P);
+            exch<1, true>(r, lds, tidv);
+            hook();
+            stages<2, false>(r, tidv, tw, P);
+            exch<2, true>(r, lds, tidv);   // the one barrier sits between its scatter and its gather
+            stages<3, NORM>(r, tidv, tw, P);
+        }
+    }
+
+    static __device__ __forceinline__ void run(T *__restrict__ data, const TwPair<T> *__restrict__ tw, const ModParams<T> &P,
+                                               uint32_t nsub, T *lds) {
+        using PF = Pf<LOAD_RM>;
+        constexpr uint32_t CML = FULL & ~LOAD_RM, CMS = FULL & ~STORE_RM;
+        constexpr int NST = E / nv<STORE_RM>();  // store instructions per polynomial (younger than the prefetch)
+        const uint32_t tid = threadIdx.x;
+        T r[E];
+#pragma unroll
+        for (int j = 0; j < E; ++j) r[j] = 0;
+        uint32_t tile = blockIdx.x;
+        // The first polynomial takes the same asynchronous path as every later one.  A plain C++ load here would leave
+        // hipcc's vmcnt model with loads "in flight" at the loop header: it then waits for them INSIDE the loop, with
+        // counts that on every later iteration drain the prefetch of the next polynomial right after it was issued
+        // (no overlap of HBM and butterflies at all: measured 102 instead of 80 ns per polynomial at N = 16384).
+        if constexpr (!(CNTT_BLK_LAB & (4 | 16))) {
+            if (tile < nsub) {
+                typename PF::V v0[PF::NVEC];
+                PF::issue(v0, (const T *)(data + ((size_t)tile << LOGN)), pdep<CML>(tid) * (uint32_t)sizeof(T));
+                PF::template wait<0>(v0);
+                PF::unpack(r, v0);
+            }
+        }
+        for (; tile < nsub; tile += gridDim.x) {
+            CNTT_BLK_STAMP(0);
+            // every address of the body is recomputed from an opaque copy of the thread index: left alone hipcc hoists
+            // them all out of the loop and spills (128 VGPRs: sixteen wavefronts per CU)
+            uint32_t tidv = tid;
+            asm volatile("" : "+v"(tidv));
+            const uint32_t tnext = tile + gridDim.x;
+            const bool more = tnext < nsub;  // workgroup-uniform
+            T *tbase = data + ((size_t)tile << LOGN);
+            typename PF::V vn[PF::NVEC];
+            if constexpr (CNTT_BLK_LAB & 16) {
+            } else if constexpr (CNTT_BLK_LAB & 4) {
+                B::template gather_tile<LOAD_RM>(r, (const T *)(data + ((size_t)tile << LOGN)), pdep<CML>(tidv) * (uint32_t)sizeof(T));
+            }
+            auto prefetch = [&]() {
+                if constexpr (!(CNTT_BLK_LAB & (4 | 16))) {
+                    if (more) PF::issue(vn, (const T *)(data + ((size_t)((CNTT_BLK_LAB & 64) ? (tnext & 255u) : tnext) << LOGN)), pdep<CML>(tidv) * (uint32_t)sizeof(T));
+                }
+            };
+#pragma unroll
+            for (int j = 0; j < E; ++j) r[j] = Bfly<T, CLS>::load_fix(r[j], P);
+            if constexpr (!INV) {
+                transform<false>(r, lds, tidv, tw, P, prefetch);
+#pragma unroll
+                for (int j = 0; j < E; ++j) r[j] = Bfly<T, CLS>::finish_fwd(r[j], P);
+                if constexpr (STORE_RM != RM3) {
+                    xsync<true>();  // block transpose into the coalesced layout (wave-private)
+                    if constexpr (!(CNTT_BLK_LAB & 8)) B::template scatter<RM3>(r, lds, pdep<FULL & ~RM3>(tidv), true);
+                    xsync<true>();
+                    if constexpr (!(CNTT_BLK_LAB & 8)) B::template gather<BLK_IO>(r, (const T *)lds, pdep<CMS>(tidv), true);
+                }
+            } else {
+                xsync<false>();  // everybody has read the previous polynomial's transpose
+                if constexpr (LOAD_RM != RM0) {
+                    if constexpr (!(CNTT_BLK_LAB & 8)) B::template scatter<BLK_IO>(r, lds, pdep<CML>(tidv), true);
+                    xsync<true>();
+                    if constexpr (!(CNTT_BLK_LAB & 8)) B::template gather<RM0>(r, (const T *)lds, pdep<FULL & ~RM0>(tidv), true);
+                }
+                transform<false>(r, lds, tidv, tw, P, prefetch);
+#pragma unroll
+                for (int j = 0; j < E; ++j) r[j] = Bfly<T, CLS>::finish_inv(r[j], P);
+            }
+            if constexpr (CNTT_BLK_LAB & (16 | 32)) {
+                if (r[0] == 0x123456789ull) tbase[tid] = r[1] ^ r[2] ^ r[3] ^ r[4] ^ r[5] ^ r[6] ^ r[7] ^ r[8] ^ r[9] ^ r[10] ^ r[11] ^ r[12] ^ r[13] ^ r[14] ^ r[15];
+            } else
+            CNTT_BLK_STAMP(9);
+#ifdef CNTT_BLK_NT
+            {
+                constexpr int NVS = nv<STORE_RM>();
+                using VS = typename VecOf<T, NVS>::type;
+                const uint32_t so = pdep<CMS>(tidv) * (uint32_t)sizeof(T);
+#pragma unroll
+                for (int j = 0; j < E; j += NVS) {
+                    VS v;
+                    if constexpr (NVS == 1) v = r[j];
+                    else { v[0] = r[j]; v[1] = r[j + 1]; }
+                    __builtin_nontemporal_store(v, reinterpret_cast<VS *>(reinterpret_cast<char *>(tbase) + so + cdep((uint32_t)j, STORE_RM) * (uint32_t)sizeof(T)));
+                }
+            }
+#else
+                B::template scatter_tile<STORE_RM>(r, tbase, pdep<CMS>(tidv) * (uint32_t)sizeof(T));
+#endif
+            CNTT_BLK_STAMP(6);
+            if constexpr (!(CNTT_BLK_LAB & (4 | 16))) {
+                if (more) {
+                    PF::template wait<NST>(vn);
+                    PF::unpack(r, vn);
+                }
+            }
+            CNTT_BLK_STAMP(7);
+        }
+    }
+};
+
+template <class T, int LOGN, bool INV, int CLS, int WPW, int TWC = 2>
+__global__ __launch_bounds__((NttBlk<T, LOGN, INV, CLS>::WPB), WPW) void ntt_kernel_blk(T *__restrict__ data,
+                                                                                     const TwPair<T> *__restrict__ tw,
+                                                                                     const ModParams<T> P, uint32_t nsub) {
+    using K = NttBlk<T, LOGN, INV, CLS, TWC>;
+    __shared__ __attribute__((aligned(16))) T lds[(size_t)1 << LOGN];
+    K::run(data, tw, P, nsub, lds);
+}
+
+// -------------------------------------------------------------------------------------------------
+// Fused negacyclic product against a pre-transformed operand on the wave-block walk (the large-N counterpart of MulWp):
+//     lhs <- inv( mul_assign_normalize( fwd(lhs), rhs_ntt ) )        src/prime64.rs:794, :947-1033, :872
+// The forward transform ends and the inverse transform starts inside a wavefront's own 1024-word block (mirror
+// schedules: the forward's last register layout is the inverse's first), so the pointwise product happens in registers
+// between them and a polynomial crosses THREE workgroup barriers for two transforms; 1/N rides in the last inverse
+// stage (Bfly::inv_norm).  3 N words of HBM traffic instead of 7 N.
+// -------------------------------------------------------------------------------------------------
+// PREFETCH: the next polynomial's lhs is loaded asynchronously into registers during the inverse transform's last two
+// passes (a kernel whose shape cannot hold it without spilling must run without: an asynchronous load must never meet a
+// spilled register -- the CPU tests read the code objects).
+template <class T, int LOGN, int CLS, int TWC = 2, bool PREFETCH = true>
+struct MulBlk {
+    using F = NttBlk<T, LOGN, false, CLS, TWC>;
+    using I = NttBlk<T, LOGN, true, CLS, TWC>;
+    using FB = typename F::B;
+    static constexpr int E = F::E, WPB = F::WPB;
+    static constexpr uint32_t FULL = F::FULL;
+    static constexpr uint32_t RMIO = F::RM0;                    // HBM layout of lhs: the top pass's own (fwd loads, inv stores)
+    static constexpr uint32_t RMM = F::RM3;                     // NTT-domain layout (inside a wavefront's block)
+    static_assert(RMM == I::RM0 && RMIO == I::RM3, "forward and inverse schedules must mirror each other");
+
+    static __device__ __forceinline__ void run(T *__restrict__ lhs, const T *__restrict__ rhs_ntt,
+                                               const TwPair<T> *__restrict__ twf, const TwPair<T> *__restrict__ twi,
+                                               const ModParams<T> &P, uint32_t nsub, T *lds) {
+        using PF = typename F::template Pf<RMIO>;
+        constexpr uint32_t CMIO = FULL & ~RMIO, CMM = FULL & ~RMM;
+        constexpr int NST = E / F::template nv<RMIO>();
+        const uint32_t tid = threadIdx.x;
+        T r[E];
+#pragma unroll
+        for (int j = 0; j < E; ++j) r[j] = 0;
+        uint32_t tile = blockIdx.x;
+        if constexpr (PREFETCH) {
+            if (tile < nsub) {  // asynchronous like every later polynomial (see NttBlk::run)
+                typename PF::V v0[PF::NVEC];
+                PF::issue(v0, (const T *)(lhs + ((size_t)tile << LOGN)), pdep<CMIO>(tid) * (uint32_t)sizeof(T));
+                PF::template wait<0>(v0);
+                PF::unpack(r, v0);
+            }
+        }
+        for (; tile < nsub; tile += gridDim.x) {
+            uint32_t tidv = tid;
+            asm volatile("" : "+v"(tidv));
+            const uint32_t tnext = tile + gridDim.x;
+            const bool more = tnext < nsub;
+            T *tbase = lhs + ((size_t)tile << LOGN);
+            typename PF::V vn[PF::NVEC];
+            if constexpr (!PREFETCH) FB::template gather_tile<RMIO>(r, (const T *)tbase, pdep<CMIO>(tidv) * (uint32_t)sizeof(T));
+            // issued where the inverse transform's scalar-twiddle passes begin (NttBlk::transform): in flight -- and live
+            // in registers -- across its last two passes only, clear of the products and of every thread-dependent twiddle
+            auto prefetch = [&]() {
+                if constexpr (PREFETCH) {
+                    if (more) PF::issue(vn, (const T *)(lhs + ((size_t)tnext << LOGN)), pdep<CMIO>(tidv) * (uint32_t)sizeof(T));
+                }
+            };
+#pragma unroll
+            for (int j = 0; j < E; ++j) r[j] = Bfly<T, CLS>::load_fix(r[j], P);
+            F::transform(r, lds, tidv, twf, P);
+            if constexpr (!Bfly<T, CLS>::FUSED_LAZY) {
+#pragma unroll
+                for (int j = 0; j < E; ++j) r[j] = Bfly<T, CLS>::finish_fwd(r[j], P);
+            }
+            {
+                // rhs_ntt is taken four coefficients at a time, the loads of the next four in flight behind the products of
+                // the current ones, with the phases pinned (asm statements on r, compiler-level fences around the loads):
+                // left alone hipcc overlaps the forward transform's tail, all sixteen products and the inverse transform's
+                // head, needs 160 VGPRs, and at the 128 of this shape spills the destinations of the prefetch in flight.
+                constexpr int CH = 4, NCH = E / CH;
+                const T *rt = rhs_ntt + ((size_t)tile << LOGN);
+                const uint32_t roff = pdep<CMM>(tidv) * (uint32_t)sizeof(T);
+#pragma unroll
+                for (int j = 0; j < E; ++j) asm volatile("" : "+v"(r[j]));
+                T bc[2][CH];
+                asm volatile("" ::: "memory");
+                FB::template gather_tile_part<RMM, 0, CH>(bc[0], rt, roff);
+                static_for<0, NCH>([&](auto c) {
+                    constexpr int C = decltype(c)::value;
+                    asm volatile("" ::: "memory");
+                    if constexpr (C + 1 < NCH) FB::template gather_tile_part<RMM, (C + 1) * CH, CH>(bc[(C + 1) & 1], rt, roff);
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int i = 0; i < CH; ++i) {
+                        r[C * CH + i] = mul_for_inv<T, CLS>(r[C * CH + i], bc[C & 1][i], P);  // 1/N: inside the last inverse stage
+                        asm volatile("" : "+v"(r[C * CH + i]));
+                    }
+                });
+            }
+            // the inverse starts in the wavefront's own block: nothing of another wavefront is touched until its transpose
+            I::template transform<true>(r, lds, tidv, twi, P, prefetch);
+#pragma unroll
+            for (int j = 0; j < E; ++j) r[j] = Bfly<T, CLS>::finish_inv(r[j], P);
+            FB::template scatter_tile<RMIO>(r, tbase, pdep<CMIO>(tidv) * (uint32_t)sizeof(T));
+            if constexpr (PREFETCH) {
+                if (more) {
+                    PF::template wait<NST>(vn);
+                    PF::unpack(r, vn);
+                }
+            }
+        }
+    }
+};
+
+template <class T, int LOGN, int CLS, int WPW, int TWC = 2, bool PREFETCH = true>
+__global__ __launch_bounds__((MulBlk<T, LOGN, CLS>::WPB), WPW) void mul_kernel_blk(T *__restrict__ lhs, const T *__restrict__ rhs_ntt,
+                                                                                const TwPair<T> *__restrict__ twf,
+                                                                                const TwPair<T> *__restrict__ twi,
+                                                                                const ModParams<T> P, uint32_t nsub) {
+    using K = MulBlk<T, LOGN, CLS, TWC, PREFETCH>;
+    __shared__ __attribute__((aligned(16))) T lds[(size_t)1 << LOGN];
+    K::run(lhs, rhs_ntt, twf, twi, P, nsub, lds);
+}
+
+}  // namespace cntt

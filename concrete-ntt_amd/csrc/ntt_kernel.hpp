@@ -169,6 +169,23 @@ struct NttKernel {
             }
         }
     }
+    // elements [J0, J0 + CNT) of the same layout (fused kernels that take an operand a few vectors at a time)
+    template <uint32_t RM, int J0, int CNT> static __device__ __forceinline__ void gather_tile_part(T (&r)[CNT], const T *tile, uint32_t voff) {
+        constexpr int NV = vec_elems<RM>();
+        using V = typename VecOf<T, NV>::type;
+        static_assert(J0 % NV == 0 && CNT % NV == 0, "whole vectors");
+#pragma unroll
+        for (int j = 0; j < CNT; j += NV) {
+            const uint32_t off = voff + cdep((uint32_t)(J0 + j), RM) * (uint32_t)sizeof(T);
+            if constexpr (NV == 1) {
+                r[j] = *reinterpret_cast<const T *>(reinterpret_cast<const char *>(tile) + off);
+            } else {
+                const V v = *reinterpret_cast<const V *>(reinterpret_cast<const char *>(tile) + off);
+#pragma unroll
+                for (int i = 0; i < NV; ++i) r[j + i] = v[i];
+            }
+        }
+    }
     template <uint32_t RM> static __device__ __forceinline__ void scatter_tile(const T (&r)[E], T *tile, uint32_t voff) {
         constexpr int NV = vec_elems<RM>();
         using V = typename VecOf<T, NV>::type;
@@ -323,6 +340,45 @@ struct NttKernel {
         }
     }
 
+    // one chunk of a stage's twiddles: CH consecutive values of h (the register bits above the stage bit)
+    template <int K, int GI, bool IMG, int CH>
+    static __device__ __forceinline__ void stage_twiddles(TwPair<T> (&w)[CH], int h0, uint32_t toff, uint32_t tid, const TwPair<T> *img,
+                                                          const TwPair<T> *__restrict__ tw) {
+        constexpr uint32_t RM = S::RMASK[K], GM = S::GMASK[K];
+        constexpr int b = nth_stage_bit(GM, GI), k = crank(RM, b);
+        constexpr StageGeom g = geom(K, GI);
+#pragma unroll
+        for (int hh = 0; hh < CH; ++hh) {
+            const int h = h0 + hh;
+            if constexpr (IMG && !g.uniform)
+                w[hh] = img[img_off(K, GI) + h * g.d + (tid >> g.shift)];
+            else  // uniform table base + 32-bit byte offset: the saddr form of global_load, no 64-bit VGPR address
+                w[hh] = *reinterpret_cast<const TwPair<T> *>(
+                    reinterpret_cast<const char *>(tw) + (toff + (cdep((uint32_t)h << (k + 1), RM) >> (b + 1))) * (uint32_t)sizeof(TwPair<T>));
+        }
+    }
+    // the butterflies of the stage whose twiddle index h lies in [h0, h0 + CH)
+    template <int K, int GI, int CH, bool UNI, class R>
+    static __device__ __forceinline__ void stage_butterflies(R (&r)[E], const TwPair<T> (&w)[CH], int h0, const ModParams<T> &P) {
+        constexpr uint32_t RM = S::RMASK[K], GM = S::GMASK[K];
+        constexpr int b = nth_stage_bit(GM, GI), k = crank(RM, b);
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            if ((j >> k) & 1) continue;
+            const int h = j >> (k + 1);
+            if (h < h0 || h >= h0 + CH) continue;
+            // twiddles that do not depend on the thread come from scalar loads and stay in SGPRs (never for the
+            // sub-block kernels: their table prefix depends on the polynomial a thread works on)
+            if constexpr (!std::is_same<R, T>::value) {
+                if constexpr (INV) BoxOps<CLS>::template inv<UNI>(r[j], r[j | (1 << k)], w[h - h0].w, w[h - h0].ws, P);
+                else BoxOps<CLS>::template fwd<UNI>(r[j], r[j | (1 << k)], w[h - h0].w, w[h - h0].ws, P);
+            } else if constexpr (INV)
+                Bfly<T, CLS>::template inv<UNI>(r[j], r[j | (1 << k)], w[h - h0].w, w[h - h0].ws, P);
+            else
+                Bfly<T, CLS>::template fwd<UNI>(r[j], r[j | (1 << k)], w[h - h0].w, w[h - h0].ws, P);
+        }
+    }
+
     // NORM (inverse only): the stage on the top index bit -- the last one, one twiddle inv_twid[1] for all of its
     // butterflies -- also applies the 1/N normalisation (Bfly::inv_norm).
     // R: the register form of a coefficient -- T itself, or (32-bit lazy class) a 64-bit "box" whose low word is the
@@ -352,38 +408,63 @@ struct NttKernel {
         // Twiddles of the stage, TWC at a time (TWC = 0: all NHI at once): bounds the registers the thread-dependent
         // twiddle loads hold (global-memory twiddles of the large sizes; workgroup shapes compiled for 128 VGPRs).
         constexpr StageGeom g = geom(K, GI);
-        constexpr bool UNI = g.uniform && !SUB;
+        // FAM 2 (wave blocks): the thread-id bits above the stage bit are wavefront-index bits only (the six lane bits
+        // sit at or below it), so the twiddle index is wave-uniform: scalar loads, SGPR operands.
+        constexpr bool WAVE_UNI = FAM == 2 && !SUB && !g.uniform && g.shift >= 6 && TPP >= 64;
+        if constexpr (WAVE_UNI) toff = (uint32_t)__builtin_amdgcn_readfirstlane((int)toff);
+        constexpr bool UNI = (g.uniform && !SUB) || WAVE_UNI;
         constexpr bool CHUNKED = TWC > 0 && !UNI && NHI > TWC;
         constexpr int CH = CHUNKED ? TWC : NHI;
+        if constexpr (CHUNKED && FAM == 2) {
+            // Double-buffered chunks (wave-block kernels): the loads of chunk c + 1 are in flight behind the butterflies of
+            // chunk c.  The waves of a workgroup run these passes in step behind their barrier, so a load waited for right
+            // after its issue idles the whole SIMD for an L2 round trip, once per chunk.
+            TwPair<T> wa[CH], wb[CH];
+            stage_twiddles<K, GI, IMG, CH>(wa, 0, toff, tid, img, tw);
 #pragma unroll
-        for (int h0 = 0; h0 < NHI; h0 += CH) {
-            TwPair<T> w[CH];
-#pragma unroll
-            for (int hh = 0; hh < CH; ++hh) {
-                const int h = h0 + hh;
-                if constexpr (IMG && !g.uniform)
-                    w[hh] = img[img_off(K, GI) + h * g.d + (tid >> g.shift)];
-                else  // uniform table base + 32-bit byte offset: the saddr form of global_load, no 64-bit VGPR address
-                    w[hh] = *reinterpret_cast<const TwPair<T> *>(
-                        reinterpret_cast<const char *>(tw) +
-                        (toff + (cdep((uint32_t)h << (k + 1), RM) >> (b + 1))) * (uint32_t)sizeof(TwPair<T>));
+            for (int h0 = 0; h0 < NHI; h0 += 2 * CH) {
+                if (h0 + CH < NHI) stage_twiddles<K, GI, IMG, CH>(wb, h0 + CH, toff, tid, img, tw);
+                __builtin_amdgcn_sched_barrier(0);
+                stage_butterflies<K, GI, CH, UNI, R>(r, wa, h0, P);
+                __builtin_amdgcn_sched_barrier(0);
+                if (h0 + CH < NHI) {
+                    if (h0 + 2 * CH < NHI) stage_twiddles<K, GI, IMG, CH>(wa, h0 + 2 * CH, toff, tid, img, tw);
+                    __builtin_amdgcn_sched_barrier(0);
+                    stage_butterflies<K, GI, CH, UNI, R>(r, wb, h0 + CH, P);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
+        } else {
 #pragma unroll
-            for (int j = 0; j < E; ++j) {
-                if ((j >> k) & 1) continue;
-                const int h = j >> (k + 1);
-                if (h < h0 || h >= h0 + CH) continue;
-                // twiddles that do not depend on the thread come from scalar loads and stay in SGPRs (never for the
-                // sub-block kernels: their table prefix depends on the polynomial a thread works on)
-                if constexpr (!std::is_same<R, T>::value) {
-                    if constexpr (INV) BoxOps<CLS>::template inv<UNI>(r[j], r[j | (1 << k)], w[h - h0].w, w[h - h0].ws, P);
-                    else BoxOps<CLS>::template fwd<UNI>(r[j], r[j | (1 << k)], w[h - h0].w, w[h - h0].ws, P);
-                } else if constexpr (INV)
-                    Bfly<T, CLS>::template inv<UNI>(r[j], r[j | (1 << k)], w[h - h0].w, w[h - h0].ws, P);
-                else
-                    Bfly<T, CLS>::template fwd<UNI>(r[j], r[j | (1 << k)], w[h - h0].w, w[h - h0].ws, P);
+            for (int h0 = 0; h0 < NHI; h0 += CH) {
+                TwPair<T> w[CH];
+#pragma unroll
+                for (int hh = 0; hh < CH; ++hh) {
+                    const int h = h0 + hh;
+                    if constexpr (IMG && !g.uniform)
+                        w[hh] = img[img_off(K, GI) + h * g.d + (tid >> g.shift)];
+                    else  // uniform table base + 32-bit byte offset: the saddr form of global_load, no 64-bit VGPR address
+                        w[hh] = *reinterpret_cast<const TwPair<T> *>(
+                            reinterpret_cast<const char *>(tw) +
+                            (toff + (cdep((uint32_t)h << (k + 1), RM) >> (b + 1))) * (uint32_t)sizeof(TwPair<T>));
+                }
+#pragma unroll
+                for (int j = 0; j < E; ++j) {
+                    if ((j >> k) & 1) continue;
+                    const int h = j >> (k + 1);
+                    if (h < h0 || h >= h0 + CH) continue;
+                    // twiddles that do not depend on the thread come from scalar loads and stay in SGPRs (never for the
+                    // sub-block kernels: their table prefix depends on the polynomial a thread works on)
+                    if constexpr (!std::is_same<R, T>::value) {
+                        if constexpr (INV) BoxOps<CLS>::template inv<UNI>(r[j], r[j | (1 << k)], w[h - h0].w, w[h - h0].ws, P);
+                        else BoxOps<CLS>::template fwd<UNI>(r[j], r[j | (1 << k)], w[h - h0].w, w[h - h0].ws, P);
+                    } else if constexpr (INV)
+                        Bfly<T, CLS>::template inv<UNI>(r[j], r[j | (1 << k)], w[h - h0].w, w[h - h0].ws, P);
+                    else
+                        Bfly<T, CLS>::template fwd<UNI>(r[j], r[j | (1 << k)], w[h - h0].w, w[h - h0].ws, P);
+                }
+                if constexpr (CHUNKED) __builtin_amdgcn_sched_barrier(0);  // keep the chunks (and their registers) apart
             }
-            if constexpr (CHUNKED) __builtin_amdgcn_sched_barrier(0);  // keep the chunks (and their registers) apart
         }
         if constexpr (Bfly<T, CLS>::IS_FP) {
             // range reductions of the double-held residues (bounds and periods: BflyFp in ntt_arith.hpp).  The last
@@ -501,6 +582,59 @@ struct NttWp : NttKernel<T, LOGN, INV, CLS, false, FAM> {
         }
     }
 
+#ifdef CNTT_LAB_XLANE
+    // Four (register bit <-> lane bit) transpositions of 16 64-bit coefficients, the shape of the N = 1024 transform's last
+    // exchange (lane bits 5, 4 or 2, 1, 0): v_permlane32_swap / v_permlane16_swap move a register pair's halves in one
+    // instruction per 32-bit word (16 each); the lane bits inside a row of 16 need a DPP move plus a select per word and
+    // direction (2 x 16 each for quad_perm bits 0 and 1).  Lab only.
+    static __device__ __forceinline__ void xlane_exchange(T (&r)[E]) {
+        uint32_t w[2 * E];
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            w[2 * j] = (uint32_t)r[j];
+            w[2 * j + 1] = (uint32_t)(r[j] >> 32);
+        }
+        const bool b0 = threadIdx.x & 1, b1 = threadIdx.x & 2;
+#pragma unroll
+        for (int j = 0; j < E; j += 2) {   // register bit 0 <-> lane bit 5, then register bit 1 <-> lane bit 4
+#pragma unroll
+            for (int h = 0; h < 2; ++h) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(w[2 * j + h]), "+v"(w[2 * (j + 1) + h]));
+        }
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            if (j & 2) continue;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(w[2 * j + h]), "+v"(w[2 * (j + 2) + h]));
+        }
+#pragma unroll
+        for (int j = 0; j < E; ++j) {      // register bit 2 <-> lane bit 0 (quad_perm [1,0,3,2]), register bit 3 <-> lane bit 1 ([2,3,0,1])
+            if (j & 4) continue;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t a = w[2 * j + h], c = w[2 * (j + 4) + h];
+                const uint32_t ta = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c, 0xb1, 0xf, 0xf, false);
+                const uint32_t tc = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, 0xb1, 0xf, 0xf, false);
+                w[2 * j + h] = b0 ? ta : a;
+                w[2 * (j + 4) + h] = b0 ? c : tc;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            if (j & 8) continue;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t a = w[2 * j + h], c = w[2 * (j + 8) + h];
+                const uint32_t ta = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c, 0x4e, 0xf, 0xf, false);
+                const uint32_t tc = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, 0x4e, 0xf, 0xf, false);
+                w[2 * j + h] = b1 ? ta : a;
+                w[2 * (j + 8) + h] = b1 ? c : tc;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < E; ++j) r[j] = (T)w[2 * j] | ((T)w[2 * j + 1] << 32);
+    }
+#endif
+
     // IMG: thread-dependent twiddles come from the workgroup's LDS image (fill_image); otherwise from the table in
     // global memory (L2), for kernels that walk several primes and cannot hold an image per prime
     // FIN: bring the outputs into [0, p) (what memory holds); fused kernels whose next step takes the class's lazy
@@ -510,8 +644,20 @@ struct NttWp : NttKernel<T, LOGN, INV, CLS, false, FAM> {
                                                 const TwPair<T> *img, const ModParams<T> &P) {
         constexpr uint32_t RM = S::RMASK[K], CM = FULL & ~RM;
         const uint32_t ebase = pdep<CM>(tid);
+#ifdef CNTT_LAB_XLANE
+        // tools/ntt_lab.hip, TIMING ONLY (wrong results): the LAST exchange of a wave-private transform as cross-lane
+        // register traffic with the instruction mix of a correct implementation (see xlane_exchange) instead of LDS
+        constexpr bool XL = B::WAVE_PRIVATE && sizeof(T) == 8 && NPASS >= 2;
+        if constexpr (K > 0 && !(XL && K == NPASS - 1)) B::template gather<RM>(r, (const T *)lds, ebase, true);
+        B::template stages<K, 0, IMG, NORM, TWC>(r, ebase, 0u, 0u, tw, P, tid, img);
+        if constexpr (XL && K == NPASS - 2) {
+            xlane_exchange(r);
+            pass<K + 1, NORM, IMG, FIN, TWC>(r, lds, tid, tw, img, P);
+        } else
+#else
         if constexpr (K > 0) B::template gather<RM>(r, (const T *)lds, ebase, true);
         B::template stages<K, 0, IMG, NORM, TWC>(r, ebase, 0u, 0u, tw, P, tid, img);
+#endif
         if constexpr (K < NPASS - 1) {
             if constexpr (K > 0) wsync();
             B::template scatter<RM>(r, lds, ebase, true);
@@ -552,9 +698,18 @@ struct NttWp : NttKernel<T, LOGN, INV, CLS, false, FAM> {
 #pragma unroll
         for (int j = 0; j < E; ++j) r[j] = 0;
         uint32_t tile = blockIdx.x;
+        // The first tile takes the same asynchronous path as every later one: plain C++ loads here leave hipcc's vmcnt
+        // model with loads in flight at the loop header, and the waits it then places INSIDE the loop drain the next
+        // tile's prefetch right after it was issued on every later iteration (no overlap of HBM and butterflies;
+        // tests/test_async_load_guard.py now measures the distance between every prefetch and its retiring wait).
         if (tile < ntiles) {
-            const uint32_t sub = tile * PPB + pl;
-            if (sub < nsub) B::template gather_tile<IO_RM>(r, (const T *)(data + (((size_t)tile * PPB) << LOGN)), voffIO);
+            const uint32_t last = nsub - 1u - tile * PPB;   // ragged tail: clamp to the last polynomial (in range)
+            const uint32_t pl0 = pl < last ? pl : last;
+            typename B::AsyncVec v0[E / B::MAXV];
+            B::template gather_async<IO_RM>(v0, (const T *)(data + (((size_t)tile * PPB) << LOGN)),
+                                            ((pl0 << LOGN) + ebaseIO) * (uint32_t)sizeof(T));
+            B::template wait_async<0>(v0);
+            B::unpack_async(r, v0);
         }
         constexpr int NST = E / B::template vec_elems<IO_RM>();  // store instructions per tile (younger than the prefetch)
         for (; tile < ntiles; tile += gridDim.x) {
@@ -615,18 +770,6 @@ __global__ __launch_bounds__(WPB, WPW) void ntt_kernel_wp(T *__restrict__ data, 
     K::run(data, tw, P, nsub, lds, img);
 }
 
-// The same persistent, software-pipelined walk for the sizes whose twiddle image does not fit LDS (u64 N >= 4096,
-// u32 N >= 8192): one polynomial per workgroup of N / E threads (up to 1024), exchange buffer only, twiddles from L2.
-// What it buys over ntt_kernel is the overlap of a polynomial's HBM reads and writes with the butterflies of its
-// neighbours: with one 128 KiB polynomial per CU nothing else hides them.
-template <class T, int LOGN, bool INV, int CLS, int WPB, int WPW>
-__global__ __launch_bounds__(WPB, WPW) void ntt_kernel_wpg(T *__restrict__ data, const TwPair<T> *__restrict__ tw,
-                                                       const ModParams<T> P, uint32_t nsub) {
-    using K = NttWp<T, LOGN, INV, CLS, WPB>;
-    __shared__ __attribute__((aligned(16))) T lds[(size_t)K::PPB << LOGN];
-    K::template run<false>(data, tw, P, nsub, lds, nullptr);
-}
-
 // -------------------------------------------------------------------------------------------------
 // Fused negacyclic product against a pre-transformed operand (the K1 -> K3 -> K2 pipeline of SURVEY 2.1):
 //     lhs <- inv( mul_assign_normalize( fwd(lhs), rhs_ntt ) )
@@ -665,9 +808,14 @@ struct MulWp {
 #pragma unroll
         for (int j = 0; j < E; ++j) r[j] = 0;
         uint32_t tile = blockIdx.x;
-        if (tile < ntiles) {
-            const uint32_t sub = tile * PPB + pl;
-            if (sub < nsub) FB::template gather_tile<IO_RM>(r, (const T *)(lhs + (((size_t)tile * PPB) << LOGN)), voffIO);
+        if (tile < ntiles) {  // asynchronous like every later tile (see NttWp::run)
+            const uint32_t last = nsub - 1u - tile * PPB;
+            const uint32_t pl0 = pl < last ? pl : last;
+            typename FB::AsyncVec v0[E / FB::MAXV];
+            FB::template gather_async<IO_RM>(v0, (const T *)(lhs + (((size_t)tile * PPB) << LOGN)),
+                                             ((pl0 << LOGN) + ebaseIO) * (uint32_t)sizeof(T));
+            FB::template wait_async<0>(v0);
+            FB::unpack_async(r, v0);
         }
         constexpr int NST = E / FB::template vec_elems<IO_RM>();
         for (; tile < ntiles; tile += gridDim.x) {

@@ -1,6 +1,7 @@
 // One launch of the fused product kernel (MulWp) for a fixed (T, LOGN, CLS) and its workgroup shape.  Shared by the
 // integer-class instantiation units (ntt_mul_inst.inc) and the CLS_FP unit (ntt_inst_u64_fp.hip).
 #pragma once
+#include "ntt_blk.hpp"
 #include "ntt_kernel.hpp"
 #include "ntt_launch.hpp"
 
@@ -42,6 +43,32 @@ static hipError_t mul_one(T *lhs, const T *rhs, const TwPair<T> *twf, const TwPa
     if (grid > ntiles) grid = ntiles;
     hipLaunchKernelGGL((mul_kernel_wp<T, LOGN, CLS, SH::BLOCK, SH::WAVES_PER_SIMD>), dim3(grid), dim3(SH::BLOCK), 0, stream,
                        lhs, rhs, twf, twi, P, nsub);
+    return hipGetLastError();
+}
+
+// Fused product on the wave-block walk (MulBlk): 64-bit words, N = 4096 ... 16384, every class but the Montgomery one.
+constexpr bool mul_blk_eligible(int bytes, int logn, int cls) { return bytes == 8 && logn >= 12 && logn <= 14 && cls != CLS_GENERIC; }
+// Workgroup shape per size.  The kernel wants ~150 VGPRs with the register prefetch of the next polynomial:
+//   N = 4096   256 threads, three workgroups per CU at 168 VGPRs (three waves per SIMD), prefetch on;
+//   N = 8192   512 threads, ONE workgroup per CU at 256 VGPRs (two waves per SIMD), prefetch on;
+//   N = 16384  1024 threads can only have 128 VGPRs: no register prefetch (an asynchronous load must never meet a
+//              spilled register); the polynomial's loads are exposed once per ~40 us of butterflies.
+// The CPU tests read the code objects: zero spills wherever PREFETCH is on.
+template <int LOGN, int CLS> struct MulBlkShape {
+    static constexpr int WPW = LOGN == 12 ? 3 : LOGN == 13 ? 2 : 4;
+    static constexpr int PER_CU = LOGN == 12 ? 3 : 1;
+    static constexpr bool PREFETCH = LOGN != 14 && !(LOGN == 12 && CLS == CLS_PM64);   // (2^64 - c at N = 4096: 3 spills with it)
+    static constexpr int TWC = LOGN == 14 ? 1 : 2;
+};
+template <class T, int LOGN, int CLS>
+static hipError_t mul_blk_one(T *lhs, const T *rhs, const TwPair<T> *twf, const TwPair<T> *twi, const ModParams<T> &P,
+                              uint32_t nsub, hipStream_t stream) {
+    using SH = MulBlkShape<LOGN, CLS>;
+    using K = MulBlk<T, LOGN, CLS, SH::TWC, SH::PREFETCH>;
+    uint32_t grid = (uint32_t)mul_num_cus() * SH::PER_CU;
+    if (grid > nsub) grid = nsub;
+    hipLaunchKernelGGL((mul_kernel_blk<T, LOGN, CLS, SH::WPW, SH::TWC, SH::PREFETCH>), dim3(grid), dim3(K::WPB), 0, stream, lhs, rhs,
+                       twf, twi, P, nsub);
     return hipGetLastError();
 }
 

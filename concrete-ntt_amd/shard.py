@@ -76,7 +76,7 @@ def gather_batch(shard, n, batch, dst=0, group=None, out=None):
     if _equal_shards(batch, world):
         per = (batch // world) * n
         views = [full[r * per:(r + 1) * per] for r in range(world)] if rank == dst else None
-        dist.gather(shard, gather_list=views, dst=dst, group=group)
+        dist.gather(shard.contiguous(), gather_list=views, dst=dst, group=group)
         return full
     if rank != dst:
         if shard.numel():

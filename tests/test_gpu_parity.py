@@ -262,6 +262,32 @@ def test_fused_mul_ntt_equals_three_calls(oracle, plans, oplans, bits, n, p):
             assert np.array_equal(got, oracle.negacyclic_convolution(n, p, a, b, bits))
 
 
+P50, P51, P63, SOLINAS, PM64 = 1125899904679937, 2251799813554177, 9223372036853661697, 18446744069414584321, 18446744073707716609
+
+
+@pytest.mark.parametrize("n,p", [(4096, P62), (8192, P62), (16384, P62), (4096, P50), (8192, P50), (16384, P50), (4096, P51),
+                                 (16384, P51), (4096, P63), (8192, P63), (16384, P63), (4096, SOLINAS), (8192, PM64),
+                                 (16384, SOLINAS), (16384, PM64)])
+def test_fused_mul_ntt_large_sizes(oracle, plans, oplans, n, p):
+    """The fused product on the wave-block walk (mul_kernel_blk, u64 n = 4096 ... 16384, every class but the Montgomery one,
+    which keeps the three launches): same values as fwd; mul_assign_normalize; inv of the oracle -- with more polynomials
+    than resident workgroups (several trips round the persistent loop, prefetch included) and ragged batch sizes."""
+    plan, ref = plans(64, n, p), oplans(64, n, p)
+    for batch in (1, 5, 1100 if n == 4096 else 530 if n == 8192 else 270):
+        a = oracle.fill_uniform(batch * n, p, 131 + batch, 64)
+        b = oracle.fill_uniform(batch * n, p, 197 + batch, 64)
+        want, bn = a.copy(), b.copy()
+        ref.fwd_batch(bn, 8)
+        ref.fwd_batch(want, 8)
+        ref.mul_assign_normalize(want, bn)
+        ref.inv_batch(want, 8)
+        da = to_dev(a)
+        plan.mul_ntt_batch(da, to_dev(bn))
+        got = to_host(da, plan.dtype)
+        bad = np.nonzero(got != want)[0]
+        assert bad.size == 0, "n=%d p=%d batch=%d: %d mismatches, first at %d" % (n, p, batch, bad.size, bad[0])
+
+
 NATIVE = {"native32_plan32": native32.Plan32, "native64_plan32": native64.Plan32,
           "native128_plan32": native128.Plan32, "native_binary32_plan32": native_binary32.Plan32,
           "native_binary64_plan32": native_binary64.Plan32, "native_binary128_plan32": native_binary128.Plan32,

@@ -132,22 +132,23 @@ def test_length_assert_is_a_panic():
 
 
 def test_async_load_kernels_do_not_spill(tmp_path):
-    """The persistent kernels prefetch with inline-asm global loads (csrc/ntt_kernel.hpp gather_async): a register
-    the compiler spills or reassigns while such a load is in flight would be overwritten when the data lands.
-    Read the gfx950 code objects of the units that use them and require zero spills and zero scratch."""
+    """The persistent kernels prefetch with inline-asm global loads (csrc/ntt_kernel.hpp gather_async, csrc/ntt_blk.hpp
+    Pf::issue): a register the compiler spills or reassigns while such a load is in flight would be overwritten when the
+    data lands.  Read the gfx950 code objects of the units that use them and require zero spills and zero scratch in every
+    persistent kernel -- except the one shape that is compiled WITHOUT the prefetch for exactly that reason
+    (mul_kernel_blk<..., PREFETCH = false>: N = 16384 fused product, ordinary loads only).
+    The objects are part of the build: their absence fails (a rebuild with another compiler must not skip this)."""
     import re
     import shutil
     import subprocess
     llvm = "/opt/rocm/lib/llvm/bin"
-    if not os.path.exists(os.path.join(llvm, "clang-offload-bundler")):
-        pytest.skip("ROCm LLVM tools not present")
+    assert os.path.exists(os.path.join(llvm, "clang-offload-bundler")), "ROCm LLVM tools not present"
     objdir = os.path.join(ROOT, "concrete-ntt_amd", "csrc", "_obj")
-    checked = 0
+    checked, exempt = 0, 0
     for unit in ("ntt_inst_u64_fwd", "ntt_inst_u64_inv", "ntt_inst_u32_fwd", "ntt_inst_u32_inv", "ntt_inst_u64_mul",
                  "ntt_inst_u32_mul", "ntt_inst_u64_fp", "ntt_inst_u64_fp51", "ntt_inst_u64_pm"):
         obj = os.path.join(objdir, unit + ".o")
-        if not os.path.exists(obj):
-            pytest.skip("objects not built in-tree (run __graft_entry__.build())")
+        assert os.path.exists(obj), "objects not built in-tree (run __graft_entry__.build())"
         fat, co = str(tmp_path / (unit + ".fat")), str(tmp_path / (unit + ".co"))
         subprocess.run([os.path.join(llvm, "llvm-objcopy"), "-O", "binary", "--only-section=.hip_fatbin", obj, fat], check=True)
         subprocess.run([os.path.join(llvm, "clang-offload-bundler"), "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
@@ -156,13 +157,16 @@ def test_async_load_kernels_do_not_spill(tmp_path):
                                text=True).stdout
         for blk in notes.split("- .agpr_count")[1:]:
             name = re.search(r"\.name:\s+(\S+)", blk).group(1)
-            if "_wp" not in name:
+            if "_wp" not in name and "_blk" not in name:
                 continue
             spills = int(re.search(r"\.vgpr_spill_count:\s+(\d+)", blk).group(1))
             scratch = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk).group(1))
+            if re.search(r"mul_kernel_blk.*Lb0EEEv", name):   # <..., PREFETCH = false>
+                exempt += 1
+                continue
             assert spills == 0 and scratch == 0, (name, spills, scratch)
             checked += 1
-    assert checked > 50
+    assert checked > 80 and 0 < exempt <= 6, (checked, exempt)
     shutil.rmtree(str(tmp_path), ignore_errors=True)
 
 

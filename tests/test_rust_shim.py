@@ -1,0 +1,214 @@
+"""The Rust shim (rust/src) checked without a Rust compiler (the image has none):
+
+* rust/src/ffi.rs declares EVERY entry point of include/cntt.h with the same name, arity, and per-argument kind
+  (pointer constness / depth, integer width) -- both files parsed independently here;
+* rust/src/ffi.rs is what tools/gen_rust_ffi.py generates from the header today (not stale);
+* rust/src/lib.rs uses every entry point, and offers every public item of the reference's twelve modules
+  (/root/reference/src/lib.rs:88-112) with the reference's argument lists: module, type, `try_new`, `ntt_size`, the
+  `ntt_i()` accessors the reference has, `fwd` / `fwd_binary` / `inv` / `negacyclic_polymul` with the right number and
+  type of residue slices, Clone / Debug exactly where the reference derives them.
+"""
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "cntt.h")
+FFI = os.path.join(ROOT, "rust", "src", "ffi.rs")
+LIB = os.path.join(ROOT, "rust", "src", "lib.rs")
+
+C_INT_TYPES = {"int", "cntt_mem_t", "cntt_table_t", "cntt_native_kind_t", "cntt_fwd_mode_t", "cntt_inv_mode_t"}
+C_SCALARS = {"size_t": "usize", "uint64_t": "u64", "uint32_t": "u32"}
+
+
+def c_kind(decl):
+    """'const uint64_t *rhs' -> 'const* u64'; 'void *const *residues' -> 'const* mut* void'; 'size_t n' -> 'usize'."""
+    decl = decl.replace("*", " * ")
+    toks = decl.split()
+    if toks[-1] not in ("*", "const") and len(toks) > 1 and toks[-1] not in C_INT_TYPES and toks[-1] not in C_SCALARS and not toks[-1].endswith("_t") \
+            and toks[-1] not in ("void", "char"):
+        toks = toks[:-1]   # parameter name
+    lead_const = toks[0] == "const"
+    if lead_const:
+        toks = toks[1:]
+    base, rest = toks[0], toks[1:]
+    base = "int" if base in C_INT_TYPES else C_SCALARS.get(base, base.replace("_t", "") if base.startswith("cntt_") else base)
+    consts = [lead_const]
+    if rest and rest[0] == "const":
+        consts[0] = True
+        rest = rest[1:]
+    for t in rest:
+        if t == "*":
+            consts.append(False)
+        else:
+            assert t == "const", decl
+            consts[-1] = True
+    out = base
+    for lvl in range(len(consts) - 1):
+        out = ("const* " if consts[lvl] else "mut* ") + out
+    return out
+
+
+def c_prototypes():
+    text = re.sub(r"/\*.*?\*/", " ", open(HEADER).read(), flags=re.S)
+    text = text[text.index('extern "C" {'):]
+    protos = {}
+    for m in re.finditer(r"([A-Za-z_][A-Za-z0-9_ \*]*?)\b(cntt_[a-z0-9_]+)\s*\(([^;{}]*?)\)\s*;", text):
+        ret, name, args = m.group(1).strip(), m.group(2), m.group(3).strip()
+        protos[name] = (c_kind(ret + " ret") if ret != "void" else "void",
+                        [] if args == "void" else [c_kind(a.strip()) for a in args.split(",")])
+    return protos
+
+
+def rust_kind(ty):
+    ty = ty.strip()
+    out = []
+    while ty.startswith("*"):
+        m = re.match(r"\*(const|mut)\s+(.*)", ty)
+        out.append("const* " if m.group(1) == "const" else "mut* ")
+        ty = m.group(2).strip()
+    base = {"c_int": "int", "c_void": "void", "c_char": "char"}.get(ty, ty)
+    # Rust writes the OUTERMOST pointer first; c_kind() builds innermost-first prefixes -> same reading order
+    return "".join(out) + base
+
+
+def rust_prototypes():
+    text = open(FFI).read()
+    block = text[text.index('extern "C" {'):]
+    protos = {}
+    for m in re.finditer(r"pub fn (cntt_[a-z0-9_]+)\(([^)]*)\)\s*(?:->\s*([^;]+))?;", block):
+        name, args, ret = m.group(1), m.group(2).strip(), m.group(3)
+        kinds = [rust_kind(a.split(":", 1)[1]) for a in args.split(",")] if args else []
+        protos[name] = (rust_kind(ret) if ret else "void", kinds)
+    return protos
+
+
+def test_every_entry_point_is_bound_with_matching_kinds():
+    c, r = c_prototypes(), rust_prototypes()
+    assert len(c) == 84, len(c)
+    assert sorted(c) == sorted(r), (sorted(set(c) - set(r)), sorted(set(r) - set(c)))
+    for name in c:
+        cret, cargs = c[name]
+        rret, rargs = r[name]
+        assert len(cargs) == len(rargs), name
+        # c_kind lists pointer levels innermost-first, Rust types outermost-first: compare as multisets per position by
+        # normalising both to (base, tuple of constness from the pointee outwards)
+        def norm_c(k):
+            parts = k.split()
+            return parts[-1], tuple(p for p in parts[:-1])[::-1]
+
+        def norm_r(k):
+            parts = k.split()
+            return parts[-1], tuple(p for p in parts[:-1])
+        assert norm_c(cret)[0] == norm_r(rret)[0] and len(norm_c(cret)[1]) == len(norm_r(rret)[1]), (name, cret, rret)
+        for i, (a, b) in enumerate(zip(cargs, rargs)):
+            (cb, cp), (rb, rp) = norm_c(a), norm_r(b)
+            assert cb == rb, (name, i, a, b)
+            # pointee-outwards constness must agree level by level
+            assert tuple(cp) == tuple(rp[::-1]), (name, i, a, b)
+
+
+def test_ffi_is_what_the_generator_writes_today():
+    before = open(FFI).read()
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_rust_ffi.py")], check=True, capture_output=True)
+    assert open(FFI).read() == before, "rust/src/ffi.rs is stale: run tools/gen_rust_ffi.py"
+
+
+def test_the_library_exports_what_the_binding_declares():
+    so = os.path.join(ROOT, "concrete-ntt_amd", "libcntt_hip.so")
+    assert os.path.exists(so), "libcntt_hip.so is not built (run __graft_entry__.build())"
+    syms = subprocess.run(["nm", "-D", "--defined-only", so], check=True, capture_output=True, text=True).stdout
+    exported = set(re.findall(r"\b(cntt_[a-z0-9_]+)\b", syms))
+    assert set(rust_prototypes()) <= exported
+
+
+def test_lib_uses_every_entry_point():
+    lib = open(LIB).read()
+    missing = [n for n in rust_prototypes() if not re.search(r"\b%s\b" % n, lib)]
+    assert not missing, missing
+
+
+# the reference's public native plans: (module, type) -> (kind, word, residue word, #residues, ntt_i accessors, binary, derives)
+# /root/reference/src/native32.rs:8-19,335-496  native64.rs:16-34,930-1165  native128.rs:6-17,120-349
+# native_binary32.rs:11-19,187-322  native_binary64.rs:17-29,342-521  native_binary128.rs:4-10,65-197
+NATIVE = {
+    ("native32", "Plan32"): (0, "u32", "u32", 3, 3, False, True),
+    ("native32", "Plan52"): (6, "u32", "u64", 2, 0, False, True),
+    ("native64", "Plan32"): (1, "u64", "u32", 5, 5, False, True),
+    ("native64", "Plan52"): (7, "u64", "u64", 3, 3, False, True),
+    ("native128", "Plan32"): (2, "u128", "u32", 10, 10, False, True),
+    ("native_binary32", "Plan32"): (3, "u32", "u32", 2, 0, True, True),
+    ("native_binary32", "Plan52"): (8, "u32", "u64", 1, 0, True, True),
+    ("native_binary64", "Plan32"): (4, "u64", "u32", 3, 0, True, True),
+    ("native_binary64", "Plan52"): (9, "u64", "u64", 2, 0, True, True),
+    ("native_binary128", "Plan32"): (5, "u128", "u32", 5, 0, True, False),   # derives nothing (src/native_binary128.rs:4)
+}
+
+
+def module_body(lib, name):
+    m = re.search(r"pub mod %s \{" % name, lib)
+    assert m, "module %s missing" % name
+    depth, i = 1, m.end()
+    while depth:
+        depth += {"{": 1, "}": -1}.get(lib[i], 0)
+        i += 1
+    return lib[m.end():i]
+
+
+def test_native_modules_mirror_the_reference():
+    lib = open(LIB).read()
+    kinds_in_header = dict(re.findall(r"(CNTT_NATIVE[A-Z0-9_]+) = (\d+)", open(HEADER).read()))
+    assert len(kinds_in_header) == 10
+    for (mod, ty), (kind, word, res, nres, nacc, binary, derives) in NATIVE.items():
+        body = module_body(lib, mod)
+        m = re.search(r"native_plan!\((?:\s*///[^\n]*\n)*\s*%s, (\d+), (\w+), (\w+), (\w+), (\w+),\s*accessors \[([^\]]*)\],\s*residues \[([^\]]*)\], binary (\w+), rhs (\w+)\);"
+                      % ty, body)
+        assert m, (mod, ty)
+        k, w, r, sub, getter, acc, resl, b, rhs = m.groups()
+        assert (int(k), w, r) == (kind, word, res), (mod, ty, k, w, r)
+        assert sub == ("prime32" if res == "u32" else "prime64") and getter == ("cntt_native_ntt32" if res == "u32" else "cntt_native_ntt64")
+        accs = [a.strip() for a in acc.split(",") if a.strip()]
+        assert accs == ["ntt_%d = %d" % (i, i) for i in range(nacc)], (mod, ty, accs)
+        assert [x.strip() for x in resl.split(",")] == ["mod_p%d" % i for i in range(nres)], (mod, ty)
+        assert b == ("true" if binary else "false")
+        assert ("clone_debug!(%s);" % ty in body) == derives, (mod, ty)
+    # the kind numbers used above are the header's
+    want = {"CNTT_NATIVE32_PLAN32": 0, "CNTT_NATIVE64_PLAN32": 1, "CNTT_NATIVE128_PLAN32": 2, "CNTT_NATIVE_BINARY32_PLAN32": 3,
+            "CNTT_NATIVE_BINARY64_PLAN32": 4, "CNTT_NATIVE_BINARY128_PLAN32": 5, "CNTT_NATIVE32_PLAN52": 6, "CNTT_NATIVE64_PLAN52": 7,
+            "CNTT_NATIVE_BINARY32_PLAN52": 8, "CNTT_NATIVE_BINARY64_PLAN52": 9}
+    assert {k: int(v) for k, v in kinds_in_header.items()} == want
+    # what the macro gives every native type
+    macro = lib[lib.index("macro_rules! native_plan"):lib.index("macro_rules! clone_debug")]
+    for item in ("pub fn try_new(n: usize) -> Option<Self>", "pub fn ntt_size(&self) -> usize", "pub fn fwd(&self, value: &[$w]",
+                 "pub fn inv(&self, value: &mut [$w]", "pub fn negacyclic_polymul(&self, prod: &mut [$w], lhs: &[$w], $rhs: &[$w])",
+                 "pub fn fwd_binary(&self, value: &[$w]", "negacyclic_polymul_batch"):
+        assert item in macro, item
+
+
+def test_prime_and_product_modules_mirror_the_reference():
+    lib = open(LIB).read()
+    macro = lib[lib.index("macro_rules! prime_plan"):lib.index("/// 32bit negacyclic NTT")]
+    # /root/reference/src/prime64.rs:704,779,785,794,872,947,1037,1085 (and the prime32 twins)
+    for item in ("pub fn try_new(polynomial_size: usize, modulus: $word) -> Option<Self>", "pub fn ntt_size(&self) -> usize",
+                 "pub fn modulus(&self) -> $word", "pub fn fwd(&self, buf: &mut [$word])", "pub fn inv(&self, buf: &mut [$word])",
+                 "pub fn mul_assign_normalize(&self, lhs: &mut [$word], rhs: &[$word])", "pub fn normalize(&self, values: &mut [$word])",
+                 "pub fn mul_accumulate(&self, acc: &mut [$word], lhs: &[$word], rhs: &[$word])", "impl Clone for Plan",
+                 "impl core::fmt::Debug for Plan", "unsafe impl Send for Plan", "unsafe impl Sync for Plan"):
+        assert item in macro, item
+    for mod, word in (("prime32", "u32"), ("prime64", "u64")):
+        assert re.search(r"prime_plan!\(%s, cntt_plan%s," % (word, word[1:]), module_body(lib, mod)), mod
+    assert "pub struct Solinas" in module_body(lib, "prime64") and "(1u128 << 64) - (1u128 << 32) + 1u128" in lib
+    prod = module_body(lib, "product")
+    # /root/reference/src/product.rs:124-136,153,251,257,268,273,360,885,917,935
+    for item in ("pub enum FwdMode { Generic, Bounded(u64) }", "pub enum InvMode { Replace, Accumulate }",
+                 "pub fn try_new(polynomial_size: usize, modulus: u64, factors: impl IntoIterator<Item = u64>) -> Option<Self>",
+                 "pub fn ntt_size(&self) -> usize", "pub fn modulus(&self) -> u64", "pub fn ntt_domain_len(&self) -> usize",
+                 "pub fn fwd(&self, ntt: &mut [u64], standard: &[u64], mode: FwdMode)",
+                 "pub fn inv(&self, standard: &mut [u64], ntt: &mut [u64], mode: InvMode)",
+                 "pub fn mul_assign_normalize(&self, lhs: &mut [u64], rhs: &[u64])", "pub fn normalize(&self, values: &mut [u64])",
+                 "pub fn mul_accumulate(&self, acc: &mut [u64], lhs: &[u64], rhs: &[u64])", "impl Clone for Plan"):
+        assert item in prod, item
+    for mod in ("prime32", "prime64", "native32", "native64", "native128", "native_binary32", "native_binary64", "native_binary128",
+                "product"):
+        assert re.search(r"^pub mod %s \{" % mod, lib, flags=re.M), mod

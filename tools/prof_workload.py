@@ -77,7 +77,7 @@ def prod_plan(n, primes, batch):
 
 if __name__ == "__main__":
     prime(prime64, 64, 1024, P62, 65536)       # C2: mul_kernel_wp / ntt_kernel_wp / pointwise_kernel
-    prime(prime64, 64, 16384, P62, 4096)       # C4 kernel: ntt_kernel_wpg<u64, 14>
+    prime(prime64, 64, 16384, P62, 4096)       # C4 kernel: ntt_kernel_blk<u64, 14>
     prime(prime64, 64, 4096, P62, 16384)
     prime(prime64, 64, 1024, P50, 65536)       # CLS_FP
     prime(prime64, 64, 1024, P51, 65536)       # CLS_FP51

@@ -7,7 +7,9 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/${1:-prof}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="$R/bench.py --gpus 1 --steps 200 --warmup 5"
+# --no-cpu-baseline: the CPU leg builds the oracle through make -> sh -> cc; no such exec hops (and no 12 s of all-core
+# CPU timing) inside a profiler-initialised process tree.  Build the checker BEFORE profiling, outside the profiler.
+ARGS="$R/bench.py --gpus 1 --steps 200 --warmup 5 --no-cpu-baseline"
 ZOO="$R/tools/prof_workload.py 4"
 echo "== kernel trace" | tee -a $R/gpurun_out/progress.log
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1; echo "trace rc=$?" | tee -a $R/gpurun_out/progress.log
@@ -17,4 +19,4 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_I
   echo "== pmc $pass" | tee -a $R/gpurun_out/progress.log
   timeout -k 10 300 rocprofv3 --pmc $pass --output-format csv -d $OUT/pmc_$name -- python3 $ZOO > $OUT/pmc_$name.log 2>&1; echo "pmc rc=$?" | tee -a $R/gpurun_out/progress.log
 done
-cd $R && python3 tools/summarize_prof.py $OUT > $OUT/summary.txt 2>&1; python3 tools/summarize_prof.py $OUT --json > $OUT/pmc_traffic.json 2>/dev/null; tail -40 $OUT/summary.txt
+cd $R && python3 tools/summarize_prof.py $OUT > $OUT/summary.txt 2>&1; python3 tools/summarize_prof.py $OUT --json --stamp $(python3 tools/csrc_hash.py) > $OUT/pmc_traffic.json 2>/dev/null; tail -40 $OUT/summary.txt

@@ -63,6 +63,8 @@ if as_json:
         if k in durs:
             e["avg_us_in_kernel_trace"] = sum(durs[k]) / len(durs[k])
         out[k] = e
+    if "--stamp" in sys.argv:  # source hash of the library the passes ran on (tools/csrc_hash.py = cntt_version())
+        out["csrc_hash"] = sys.argv[sys.argv.index("--stamp") + 1]
     print(json.dumps(out, indent=1, sort_keys=True))
     sys.exit(0)
 
