@@ -361,6 +361,18 @@ template <class T> static int ntt_device(const PrimePlan<T> *pl, T *d, size_t ba
     const size_t nbfly = batch * (pl->n / 2);
     const int tcls = transform_class(pl);
     hipError_t e;
+    if (depth == 1 && batch < ((size_t)1 << 32)) {
+        // one size past the LDS-resident ones: a single-pass kernel exists for 64-bit words (Ntt32k), in the plan's
+        // 64-bit-only class where it has one (those tables exist at every size)
+        int c1 = tcls;
+        if constexpr (sizeof(T) == 8) c1 = pl->mp.fp ? (int)pl->mp.fp : pl->mp.pm_c ? (int)CLS_PM64 : tcls;
+        e = inv ? launch_ntt<T, true>(pl->logn, c1, d, alt_tables(c1) ? t.inv_fp : t.inv, pl->mp, (uint32_t)batch, 0u, st)
+                : launch_ntt<T, false>(pl->logn, c1, d, alt_tables(c1) ? t.fwd_fp : t.fwd, pl->mp, (uint32_t)batch, 0u, st);
+        if (e == hipSuccess) return CNTT_OK;
+        (void)hipGetLastError();
+        if (e != hipErrorNotSupported && e != hipErrorInvalidValue)
+            return fail(CNTT_EDEVICE, "NTT kernel launch failed: %s", hipGetErrorString(e));
+    }
     if (!inv) {
         for (int s = 0; s < depth; ++s) global_stage<T, false>(d, t.fwd, pl->mp, (uint32_t)pl->logn, (uint32_t)s, nbfly, false, st);
         e = launch_ntt<T, false>(sub_logn, tcls, d, alt_tables(tcls) ? t.fwd_fp : t.fwd, pl->mp, nsub, (uint32_t)depth, st);

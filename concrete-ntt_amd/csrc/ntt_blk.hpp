@@ -31,9 +31,11 @@
 
 namespace cntt {
 
-template <class T, int LOGN, bool INV, int CLS, int TWC = 2>
+// SUB: the transform is one half of a 2^(LOGN+1)-point polynomial (Ntt32k below): table offsets as NttKernel's SUB mode
+// with depth 1 and the workgroup-uniform prefix `qpre` = half << LOGN.
+template <class T, int LOGN, bool INV, int CLS, int TWC = 2, bool SUB = false>
 struct NttBlk {
-    using B = NttKernel<T, LOGN, INV, CLS, false, 2>;
+    using B = NttKernel<T, LOGN, INV, CLS, SUB, 2>;
     using S = typename B::S;
     static_assert(sizeof(T) == 8 && B::NPASS == 4 && B::LOGE == 4, "wave-block schedules: 64-bit words, four passes of 16");
     static constexpr int E = B::E, TPP = B::TPP, WPB = B::TPP;
@@ -115,13 +117,14 @@ struct NttBlk {
     };
 
     template <int K, bool NORM>
-    static __device__ __forceinline__ void stages(T (&r)[E], uint32_t tidv, const TwPair<T> *__restrict__ tw, const ModParams<T> &P) {
+    static __device__ __forceinline__ void stages(T (&r)[E], uint32_t tidv, const TwPair<T> *__restrict__ tw, const ModParams<T> &P,
+                                                  uint32_t qpre = 0u) {
         constexpr uint32_t CM = FULL & ~S::RMASK[K];
         if constexpr (CNTT_BLK_LAB & 2) {
             B::template stages<K, 0, false, NORM, TWC>(r, 0u, 0u, 0u, tw, P, tidv, nullptr);
             return;
         }
-        B::template stages<K, 0, false, NORM, TWC>(r, pdep<CM>(tidv), 0u, 0u, tw, P, tidv, nullptr);
+        B::template stages<K, 0, false, NORM, TWC>(r, pdep<CM>(tidv), qpre, SUB ? 1u : 0u, tw, P, tidv, nullptr);
     }
     // exchange between pass K and pass K + 1
     template <int K, bool PRE_PRIV> static __device__ __forceinline__ void exch(T (&r)[E], T *lds, uint32_t tidv) {
@@ -142,31 +145,31 @@ struct NttBlk {
     };
     template <bool NORM = false, class HOOK = NoHook>
     static __device__ __forceinline__ void transform(T (&r)[E], T *lds, uint32_t tidv, const TwPair<T> *__restrict__ tw,
-                                                     const ModParams<T> &P, const HOOK &hook = HOOK{}) {
+                                                     const ModParams<T> &P, const HOOK &hook = HOOK{}, uint32_t qpre = 0u) {
         if constexpr (!INV) {
             hook();
             CNTT_BLK_STAMP(8);
-            stages<0, false>(r, tidv, tw, P);
+            stages<0, false>(r, tidv, tw, P, qpre);
             CNTT_BLK_STAMP(1);
             exch<0, false>(r, lds, tidv);  // behind everybody's last read of the previous polynomial; then the one barrier
             CNTT_BLK_STAMP(2);
-            stages<1, false>(r, tidv, tw, P);
+            stages<1, false>(r, tidv, tw, P, qpre);
             CNTT_BLK_STAMP(3);
             exch<1, true>(r, lds, tidv);
-            stages<2, false>(r, tidv, tw, P);
+            stages<2, false>(r, tidv, tw, P, qpre);
             CNTT_BLK_STAMP(4);
             exch<2, true>(r, lds, tidv);
-            stages<3, false>(r, tidv, tw, P);
+            stages<3, false>(r, tidv, tw, P, qpre);
             CNTT_BLK_STAMP(5);
         } else {
-            stages<0, false>(r, tidv, tw, P);
+            stages<0, false>(r, tidv, tw, P, qpre);
             exch<0, true>(r, lds, tidv);
-            stages<1, false>(r, tidv, tw, P);
+            stages<1, false>(r, tidv, tw, P, qpre);
             exch<1, true>(r, lds, tidv);
             hook();
-            stages<2, false>(r, tidv, tw, P);
+            stages<2, false>(r, tidv, tw, P, qpre);
             exch<2, true>(r, lds, tidv);   // the one barrier sits between its scatter and its gather
-            stages<3, NORM>(r, tidv, tw, P);
+            stages<3, NORM>(r, tidv, tw, P, qpre);
         }
     }
 
@@ -276,6 +279,108 @@ __global__ __launch_bounds__((NttBlk<T, LOGN, INV, CLS>::WPB), WPW) void ntt_ker
 }
 
 // -------------------------------------------------------------------------------------------------
+// N = 32768 (64-bit words) in ONE pass over HBM.  The 256 KiB polynomial does not fit LDS, but it fits the registers of a
+// 1024-thread workgroup (32 coefficients per thread): the stage on index bit 14 pairs coefficient e with e + 16384 and
+// needs no exchange when a thread holds both; after it the two halves are independent 16384-point transforms with table
+// offsets of their own (SUB mode, depth 1), which go through the wave-block walk above one after the other, the second
+// half parked in registers while the first one owns the 128 KiB exchange buffer.  Inverse: the mirror image.
+// Replaces global_stage_kernel + two LDS-resident sub-transforms (two passes over HBM): src/prime64/shoup.rs:660-682 is the
+// reference's own depth-first split with the same stage / twiddle indexing.  No register prefetch (the parked half takes
+// its place): a polynomial's loads are exposed once per ~50 us of butterflies.
+// -------------------------------------------------------------------------------------------------
+template <class T, bool INV, int CLS, int TWC = 1>
+struct Ntt32k {
+    static constexpr int LOGH = 14;
+    using H = NttBlk<T, LOGH, INV, CLS, TWC, true>;
+    using HB = typename H::B;
+    static constexpr int E = H::E, WPB = H::WPB;
+    static constexpr uint32_t FULL = H::FULL, TOP = INV ? H::RM3 : H::RM0;   // the top pass's layout: HBM side of a half
+    static constexpr uint32_t BLK_IO = H::BLK_IO;
+
+    static __device__ __forceinline__ void run(T *__restrict__ data, const TwPair<T> *__restrict__ tw, const ModParams<T> &P,
+                                               uint32_t nsub, T *lds) {
+        constexpr uint32_t CMT = FULL & ~TOP, CMB = FULL & ~BLK_IO;
+        const uint32_t tid = threadIdx.x;
+        const TwPair<T> w14 = tw[1];   // the stage on bit 14: one twiddle for all of its butterflies (table entry 2^0 + 0)
+        for (uint32_t tile = blockIdx.x; tile < nsub; tile += gridDim.x) {
+            uint32_t tidv = tid;
+            asm volatile("" : "+v"(tidv));
+            T *base = data + ((size_t)tile << (LOGH + 1));
+            T a[E], b[E];
+            if constexpr (!INV) {
+                HB::template gather_tile<TOP>(a, (const T *)base, pdep<CMT>(tidv) * (uint32_t)sizeof(T));
+                HB::template gather_tile<TOP>(b, (const T *)(base + ((size_t)1 << LOGH)), pdep<CMT>(tidv) * (uint32_t)sizeof(T));
+#pragma unroll
+                for (int j = 0; j < E; ++j) {
+                    a[j] = Bfly<T, CLS>::load_fix(a[j], P);
+                    b[j] = Bfly<T, CLS>::load_fix(b[j], P);
+                    Bfly<T, CLS>::template fwd<true>(a[j], b[j], w14.w, w14.ws, P);
+                    if constexpr (Bfly<T, CLS>::IS_FP) {  // the halves' reduction schedules assume inputs no larger than canonical ones
+                        a[j] = Bfly<T, CLS>::reduce(a[j], P);
+                        b[j] = Bfly<T, CLS>::reduce(b[j], P);
+                    }
+                }
+                // (the second half recomputes its addresses from a fresh opaque copy of the thread index: shared with the
+                // first half's they would all stay live across it, next to the parked coefficients)
+                uint32_t t2 = tidv;
+                asm volatile("" : "+v"(t2));
+                half_fwd(a, lds, tidv, tw, P, 0u, base);
+                half_fwd(b, lds, t2, tw, P, 1u << LOGH, base + ((size_t)1 << LOGH));
+            } else {
+                uint32_t t2 = tidv;
+                asm volatile("" : "+v"(t2));
+                half_inv(a, lds, tidv, tw, P, 0u, base);
+                half_inv(b, lds, t2, tw, P, 1u << LOGH, base + ((size_t)1 << LOGH));
+#pragma unroll
+                for (int j = 0; j < E; ++j) {
+                    if constexpr (Bfly<T, CLS>::IS_FP) {  // whatever the halves' schedules left: back to |v| <= p/2 before the sum
+                        a[j] = Bfly<T, CLS>::reduce(a[j], P);
+                        b[j] = Bfly<T, CLS>::reduce(b[j], P);
+                    }
+                    Bfly<T, CLS>::template inv<true>(a[j], b[j], w14.w, w14.ws, P);
+                    a[j] = Bfly<T, CLS>::finish_inv(a[j], P);
+                    b[j] = Bfly<T, CLS>::finish_inv(b[j], P);
+                }
+                HB::template scatter_tile<TOP>(a, base, pdep<CMT>(tidv) * (uint32_t)sizeof(T));
+                HB::template scatter_tile<TOP>(b, base + ((size_t)1 << LOGH), pdep<CMT>(tidv) * (uint32_t)sizeof(T));
+            }
+        }
+    }
+    // forward: a half (already past the stage on bit 14) through the wave-block walk, canonicalised and stored
+    static __device__ __forceinline__ void half_fwd(T (&r)[E], T *lds, uint32_t tidv, const TwPair<T> *__restrict__ tw,
+                                                    const ModParams<T> &P, uint32_t qpre, T *hbase) {
+        H::template transform<false>(r, lds, tidv, tw, P, typename H::NoHook{}, qpre);
+#pragma unroll
+        for (int j = 0; j < E; ++j) r[j] = Bfly<T, CLS>::finish_fwd(r[j], P);
+        H::template xsync<true>();  // block transpose into the coalesced layout (wave-private)
+        HB::template scatter<H::RM3>(r, lds, pdep<FULL & ~H::RM3>(tidv), true);
+        H::template xsync<true>();
+        HB::template gather<BLK_IO>(r, (const T *)lds, pdep<FULL & ~BLK_IO>(tidv), true);
+        HB::template scatter_tile<BLK_IO>(r, hbase, pdep<FULL & ~BLK_IO>(tidv) * (uint32_t)sizeof(T));
+    }
+    // inverse: a half loaded block-wise, through the walk up to (not including) the stage on bit 14; values stay lazy
+    static __device__ __forceinline__ void half_inv(T (&r)[E], T *lds, uint32_t tidv, const TwPair<T> *__restrict__ tw,
+                                                    const ModParams<T> &P, uint32_t qpre, const T *hbase) {
+        HB::template gather_tile<BLK_IO>(r, hbase, pdep<FULL & ~BLK_IO>(tidv) * (uint32_t)sizeof(T));
+#pragma unroll
+        for (int j = 0; j < E; ++j) r[j] = Bfly<T, CLS>::load_fix(r[j], P);
+        H::template xsync<false>();  // everybody has read what the buffer held (the other half's transpose)
+        HB::template scatter<BLK_IO>(r, lds, pdep<FULL & ~BLK_IO>(tidv), true);
+        H::template xsync<true>();
+        HB::template gather<H::RM0>(r, (const T *)lds, pdep<FULL & ~H::RM0>(tidv), true);
+        H::template transform<false>(r, lds, tidv, tw, P, typename H::NoHook{}, qpre);
+    }
+};
+
+template <class T, bool INV, int CLS, int WPW>
+__global__ __launch_bounds__((Ntt32k<T, INV, CLS>::WPB), WPW) void ntt_kernel_32k(T *__restrict__ data, const TwPair<T> *__restrict__ tw,
+                                                                                const ModParams<T> P, uint32_t nsub) {
+    using K = Ntt32k<T, INV, CLS>;
+    __shared__ __attribute__((aligned(16))) T lds[(size_t)1 << K::LOGH];
+    K::run(data, tw, P, nsub, lds);
+}
+
+// -------------------------------------------------------------------------------------------------
 // Fused negacyclic product against a pre-transformed operand on the wave-block walk (the large-N counterpart of MulWp):
 //     lhs <- inv( mul_assign_normalize( fwd(lhs), rhs_ntt ) )        src/prime64.rs:794, :947-1033, :872
 // The forward transform ends and the inverse transform starts inside a wavefront's own 1024-word block (mirror
@@ -364,7 +469,9 @@ struct MulBlk {
                 });
             }
             // the inverse starts in the wavefront's own block: nothing of another wavefront is touched until its transpose
-            I::template transform<true>(r, lds, tidv, twi, P, prefetch);
+            uint32_t ti = tidv;   // fresh opaque copy: no address of the forward half stays live into the inverse half
+            asm volatile("" : "+v"(ti));
+            I::template transform<true>(r, lds, ti, twi, P, prefetch);
 #pragma unroll
             for (int j = 0; j < E; ++j) r[j] = Bfly<T, CLS>::finish_inv(r[j], P);
             FB::template scatter_tile<RMIO>(r, tbase, pdep<CMIO>(tidv) * (uint32_t)sizeof(T));
@@ -386,6 +493,117 @@ __global__ __launch_bounds__((MulBlk<T, LOGN, CLS>::WPB), WPW) void mul_kernel_b
     using K = MulBlk<T, LOGN, CLS, TWC, PREFETCH>;
     __shared__ __attribute__((aligned(16))) T lds[(size_t)1 << LOGN];
     K::run(lhs, rhs_ntt, twf, twi, P, nsub, lds);
+}
+
+// -------------------------------------------------------------------------------------------------
+// Fused mul_accumulate chain on the wave-block walk (the large-N counterpart of ExtWp, ntt_kernel.hpp):
+//     for each o < NOUT:  out[b][o] (+)= inv( sum_{j < J} fwd(terms[b][j]) (.) key_ntt[j][o] )
+// i.e. the caller's  for j { plan.fwd(t_j); for o { plan.mul_accumulate(acc_o, t_j, key[j][o]) } }  for o { plan.inv(acc_o) }
+// (src/prime64.rs:794, :1085-1128, :872) with every intermediate in registers: (J + NOUT) N words of HBM traffic per batch
+// element instead of (2J + 3 J NOUT + 2 NOUT) N.  One batch element per workgroup; the NOUT accumulators live in the NTT
+// domain's block layout (each wavefront accumulates its own 1024-word block), `key_ntt` is read in that layout from L2.
+// Ordinary loads throughout (no asynchronous prefetch: the accumulators fill the register file).
+// -------------------------------------------------------------------------------------------------
+template <class T, int LOGN, int CLS, int NOUT, int TWC = 1>
+struct ExtBlk {
+    using F = NttBlk<T, LOGN, false, CLS, TWC>;
+    using I = NttBlk<T, LOGN, true, CLS, TWC>;
+    using FB = typename F::B;
+    static constexpr int E = F::E, WPB = F::WPB;
+    static constexpr uint32_t FULL = F::FULL, RMIO = F::RM0, RMM = F::RM3;
+    static_assert(RMM == I::RM0 && RMIO == I::RM3, "forward and inverse schedules must mirror each other");
+
+    static __device__ __forceinline__ void mul_acc_key(T (&acc)[E], const T (&r)[E], const T *__restrict__ key, uint32_t ebase,
+                                                       const ModParams<T> &P) {
+        constexpr int NV = FB::template vec_elems<RMM>();
+        using V = typename VecOf<T, NV>::type;
+#pragma unroll
+        for (int j = 0; j < E; j += NV) {
+            const uint32_t e = ebase | cdep((uint32_t)j, RMM);
+            if constexpr (NV == 1) {
+                acc[j] = mul_acc_cls<T, CLS>(acc[j], r[j], key[e], P);
+            } else {
+                const V v = *reinterpret_cast<const V *>(&key[e]);
+#pragma unroll
+                for (int i = 0; i < NV; ++i) acc[j + i] = mul_acc_cls<T, CLS>(acc[j + i], r[j + i], v[i], P);
+            }
+        }
+    }
+
+    static __device__ __forceinline__ void run(T *__restrict__ out, const T *__restrict__ terms, const T *__restrict__ key_ntt,
+                                               const TwPair<T> *__restrict__ twf, const TwPair<T> *__restrict__ twi,
+                                               const ModParams<T> &P, uint32_t nb, uint32_t nterms, bool accumulate, T *lds) {
+        constexpr uint32_t CMIO = FULL & ~RMIO, CMM = FULL & ~RMM;
+        const uint32_t tid = threadIdx.x;
+        for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
+            uint32_t tidv = tid;
+            asm volatile("" : "+v"(tidv));
+            const T *tb = terms + (((size_t)b * nterms) << LOGN);
+            T acc[NOUT][E];
+            static_for<0, NOUT>([&](auto o) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) acc[o.value][e] = 0;
+            });
+            for (uint32_t j = 0; j < nterms; ++j) {
+                // (addresses recomputed per term from an opaque copy of the thread index: hoisted out of this loop they
+                // would all be live across it, next to the accumulators, and spill)
+                uint32_t tj = tidv;
+                asm volatile("" : "+v"(tj));
+                T r[E];
+                FB::template gather_tile<RMIO>(r, tb + ((size_t)j << LOGN), pdep<CMIO>(tj) * (uint32_t)sizeof(T));
+#pragma unroll
+                for (int e = 0; e < E; ++e) r[e] = Bfly<T, CLS>::load_fix(r[e], P);
+                F::transform(r, lds, tj, twf, P);   // (its first exchange waits for everybody's last read of the buffer)
+                if constexpr (!Bfly<T, CLS>::FUSED_LAZY) {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) r[e] = Bfly<T, CLS>::finish_fwd(r[e], P);
+                }
+                if constexpr (Bfly<T, CLS>::IS_FP) {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) r[e] = Bfly<T, CLS>::reduce(r[e], P);
+                }
+                static_for<0, NOUT>([&](auto o) {
+                    mul_acc_key(acc[o.value], r, key_ntt + (((size_t)j * NOUT + o.value) << LOGN), pdep<CMM>(tj), P);
+                    if constexpr (Bfly<T, CLS>::IS_FP) {  // every product adds at most 0.875 p to the lazy accumulator
+                        if ((j + 1u) % (uint32_t)Bfly<T, CLS>::ACC_REDUCE_EVERY == 0u) {
+#pragma unroll
+                            for (int e = 0; e < E; ++e) acc[o.value][e] = Bfly<T, CLS>::reduce(acc[o.value][e], P);
+                        }
+                    }
+                });
+            }
+            static_for<0, NOUT>([&](auto o) {
+                T(&a)[E] = acc[o.value];
+#pragma unroll
+                for (int e = 0; e < E; ++e) a[e] = Bfly<T, CLS>::pre_inverse(a[e], P);  // lazy accumulator -> inverse input
+                // the inverse starts by writing the wavefront's own block: everybody must have finished the previous
+                // output's cross-wave gather (or the last forward transform never left the block: harmless extra wait)
+                F::template xsync<false>();
+                I::template transform<false>(a, lds, tidv, twi, P);
+#pragma unroll
+                for (int e = 0; e < E; ++e) a[e] = Bfly<T, CLS>::finish_inv(a[e], P);
+                T *dst = out + (((size_t)b * NOUT + o.value) << LOGN);
+                if (accumulate) {
+                    T old[E];
+                    FB::template gather_tile<RMIO>(old, (const T *)dst, pdep<CMIO>(tidv) * (uint32_t)sizeof(T));
+#pragma unroll
+                    for (int e = 0; e < E; ++e) a[e] = add_mod<T>(old[e], a[e], P.p);
+                }
+                FB::template scatter_tile<RMIO>(a, dst, pdep<CMIO>(tidv) * (uint32_t)sizeof(T));
+            });
+        }
+    }
+};
+
+template <class T, int LOGN, int CLS, int WPW, int NOUT>
+__global__ __launch_bounds__((ExtBlk<T, LOGN, CLS, NOUT>::WPB), WPW) void ext_kernel_blk(T *__restrict__ out, const T *__restrict__ terms,
+                                                                                   const T *__restrict__ key_ntt,
+                                                                                   const TwPair<T> *__restrict__ twf,
+                                                                                   const TwPair<T> *__restrict__ twi, const ModParams<T> P,
+                                                                                   uint32_t nb, uint32_t nterms, uint32_t accumulate) {
+    using K = ExtBlk<T, LOGN, CLS, NOUT>;
+    __shared__ __attribute__((aligned(16))) T lds[(size_t)1 << LOGN];
+    K::run(out, terms, key_ntt, twf, twi, P, nb, nterms, accumulate != 0, lds);
 }
 
 }  // namespace cntt

@@ -238,13 +238,11 @@ struct NttKernel {
                          : "memory");
         } else if constexpr (E / MAXV == 4) {
             asm volatile("s_waitcnt vmcnt(%4)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) : "n"(YOUNGER) : "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(%8)"
-                         : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])
+        } else {  // every destination vector is a tied operand of the ONE waiting statement
+            asm volatile("s_waitcnt vmcnt(%16)"
+                         : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
+                           "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15])
                          : "n"(YOUNGER)
-                         : "memory");
-            asm volatile("" : "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15])
-                         :
                          : "memory");
         }
     }
@@ -410,9 +408,11 @@ struct NttKernel {
         constexpr StageGeom g = geom(K, GI);
         // FAM 2 (wave blocks): the thread-id bits above the stage bit are wavefront-index bits only (the six lane bits
         // sit at or below it), so the twiddle index is wave-uniform: scalar loads, SGPR operands.
-        constexpr bool WAVE_UNI = FAM == 2 && !SUB && !g.uniform && g.shift >= 6 && TPP >= 64;
-        if constexpr (WAVE_UNI) toff = (uint32_t)__builtin_amdgcn_readfirstlane((int)toff);
-        constexpr bool UNI = (g.uniform && !SUB) || WAVE_UNI;
+        // (FAM 2 with SUB -- the two 16384-point halves of a 32768-point transform, ntt_blk.hpp -- keeps both: there the
+        // sub-block prefix is a workgroup-uniform constant, not a per-thread value)
+        constexpr bool WAVE_UNI = FAM == 2 && !g.uniform && g.shift >= 6 && TPP >= 64;
+        if constexpr (WAVE_UNI || (FAM == 2 && SUB && g.uniform)) toff = (uint32_t)__builtin_amdgcn_readfirstlane((int)toff);
+        constexpr bool UNI = (g.uniform && (!SUB || FAM == 2)) || WAVE_UNI;
         constexpr bool CHUNKED = TWC > 0 && !UNI && NHI > TWC;
         constexpr int CH = CHUNKED ? TWC : NHI;
         if constexpr (CHUNKED && FAM == 2) {
@@ -469,7 +469,7 @@ struct NttKernel {
         if constexpr (Bfly<T, CLS>::IS_FP) {
             // range reductions of the double-held residues (bounds and periods: BflyFp in ntt_arith.hpp).  The last
             // stage is followed by finish_*.
-            static_assert(!SUB, "the double-precision classes cover whole LDS-resident transforms only");
+            static_assert(!SUB || FAM == 2, "the double-precision classes cover whole LDS-resident transforms (and the halves of Ntt32k, which reduces around its own stage)");
             using BF = Bfly<T, CLS>;
             constexpr int SNO = stage_no(K, GI);
             if constexpr (!INV && SNO % BF::FWD_REDUCE_EVERY == BF::FWD_REDUCE_EVERY - 1 && SNO != LOGN - 1) {

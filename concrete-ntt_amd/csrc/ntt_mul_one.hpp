@@ -48,17 +48,15 @@ static hipError_t mul_one(T *lhs, const T *rhs, const TwPair<T> *twf, const TwPa
 
 // Fused product on the wave-block walk (MulBlk): 64-bit words, N = 4096 ... 16384, every class but the Montgomery one.
 constexpr bool mul_blk_eligible(int bytes, int logn, int cls) { return bytes == 8 && logn >= 12 && logn <= 14 && cls != CLS_GENERIC; }
-// Workgroup shape per size.  The kernel wants ~150 VGPRs with the register prefetch of the next polynomial:
-//   N = 4096   256 threads, three workgroups per CU at 168 VGPRs (three waves per SIMD), prefetch on;
-//   N = 8192   512 threads, ONE workgroup per CU at 256 VGPRs (two waves per SIMD), prefetch on;
-//   N = 16384  1024 threads can only have 128 VGPRs: no register prefetch (an asynchronous load must never meet a
-//              spilled register); the polynomial's loads are exposed once per ~40 us of butterflies.
-// The CPU tests read the code objects: zero spills wherever PREFETCH is on.
+// Workgroup shape: N/16 threads, four waves per SIMD (116-128 VGPRs with the register prefetch of the next polynomial --
+// it fits once the inverse half recomputes its addresses from a fresh opaque copy of the thread index instead of keeping
+// the forward half's alive), as many workgroups per CU as LDS and sixteen wavefronts allow: 4 / 2 / 1.
+// The CPU tests read the code objects: zero spills in every instance.
 template <int LOGN, int CLS> struct MulBlkShape {
-    static constexpr int WPW = LOGN == 12 ? 3 : LOGN == 13 ? 2 : 4;
-    static constexpr int PER_CU = LOGN == 12 ? 3 : 1;
-    static constexpr bool PREFETCH = LOGN != 14 && !(LOGN == 12 && CLS == CLS_PM64);   // (2^64 - c at N = 4096: 3 spills with it)
-    static constexpr int TWC = LOGN == 14 ? 1 : 2;
+    static constexpr int WPW = 4;
+    static constexpr int PER_CU = LOGN == 12 ? 4 : LOGN == 13 ? 2 : 1;
+    static constexpr bool PREFETCH = !(CLS == CLS_STRICT && LOGN != 13);   // (the strict class spills 2-4 registers with it there)
+    static constexpr int TWC = 1;
 };
 template <class T, int LOGN, int CLS>
 static hipError_t mul_blk_one(T *lhs, const T *rhs, const TwPair<T> *twf, const TwPair<T> *twi, const ModParams<T> &P,

@@ -100,7 +100,8 @@ int cntt_prime64_mul_accumulate_batch(const cntt_plan64_t *plan, uint64_t *acc, 
 /* Fused lhs <- inv(mul_assign_normalize(fwd(lhs), rhs_ntt)): the composition a caller of the reference writes as
  * plan.fwd(a); plan.mul_assign_normalize(a, b_ntt); plan.inv(a)  (examples/mul_poly_prime.rs, src/prime64.rs:1254-1266),
  * i.e. the negacyclic product of lhs with the polynomial whose forward transform is rhs_ntt, in one pass over HBM
- * for n <= 2048 (u64) / 4096 (u32), three launches otherwise.  Same values as the three separate calls. */
+ * for n <= 16384 (u64; n >= 4096 except the Montgomery-class moduli) / 4096 (u32), three launches otherwise.  Same
+ * values as the three separate calls. */
 int cntt_prime64_mul_ntt_batch(const cntt_plan64_t *plan, uint64_t *lhs, const uint64_t *rhs_ntt, size_t batch, cntt_mem_t where, void *stream);
 /* Fused mul_accumulate chain, the composition a caller of the reference writes around the NTT as
  *     for j < nterms { plan.fwd(t_j); for o < nout { plan.mul_accumulate(acc_o, t_j, key[j][o]) } }  for o { plan.inv(acc_o) }
@@ -191,7 +192,13 @@ int cntt_native_inv_batch(const cntt_native_t *plan, void *value, void *const *r
  * (independent of the batch); the Plan52 kinds and n = 32768 run the composed pipeline on a workspace of
  * 2 * nprimes * batch * n residues.  The workspace grows on demand (an allocation, and a device synchronisation when it
  * is replaced): reserve it ahead of a timed or captured region with cntt_native_reserve().  Calls on different streams
- * that share a plan are ordered against each other by the library wherever they share the workspace. */
+ * that share a plan are ordered against each other by the library wherever they share the workspace -- EXCEPT while a
+ * stream is being captured into a hipGraph: a captured launch neither waits on nor records the workspace event, and it
+ * bakes the workspace address into the graph.  Rules for captured use: reserve the largest batch BEFORE the capture and
+ * never grow the workspace afterwards (a regrow frees the buffer a captured graph still points at); do not replay such a
+ * graph concurrently with eager calls, or with other graphs, of the SAME plan on another stream (the persistent kernels
+ * park tiles at workgroup-indexed offsets of the one workspace) -- use one plan (cntt_native_plan_clone) per concurrent
+ * stream. */
 int cntt_native_negacyclic_polymul_batch(const cntt_native_t *plan, void *prod, const void *lhs, const void *rhs, size_t batch, cntt_mem_t where, void *stream);
 int cntt_native_reserve(const cntt_native_t *plan, size_t batch);
 

@@ -6,9 +6,11 @@ polynomial sizes (256 ... 32768), same nine primes and the same native plans; fo
 reference's `benchmarks_parameters/<bench_id>/parameters.json` record (benches/ntt.rs:50-81) and one result line
     {"bench_id", "ns_per_call", "calls_per_s", "batch", "algorithmic_GBps", "hbm_frac"}
 where a "call" is what criterion times in the reference (one fwd / inv / negacyclic_polymul of ONE polynomial);
-here it is the batched device-resident launch divided by the batch (operands ~256 MiB, past the Infinity Cache).
+here it is the batched device-resident launch divided by the batch.  Operands are 1 GiB each by default: four times the
+256 MiB Infinity Cache (MALL), so every pass streams from HBM (round 2 used 256 MiB operands = exactly the MALL size, and
+its HBM-leaning rows -- the double-precision classes, the pointwise kernels -- read up to 15 % high).
 
-    python tools/bench_grid.py [--out gpurun_out/bench_grid] [--mib 256] [--sizes 256,1024]
+    python tools/bench_grid.py [--out gpurun_out/bench_grid] [--mib 1024] [--sizes 256,1024]
 """
 import argparse
 import json
@@ -119,7 +121,7 @@ class Grid:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "bench_grid"))
-    ap.add_argument("--mib", type=int, default=256)
+    ap.add_argument("--mib", type=int, default=1024, help="MiB per operand (>= 512: past the 256 MiB Infinity Cache)")
     ap.add_argument("--ramp", type=float, default=0.25)
     ap.add_argument("--sizes", default="256,512,1024,2048,4096,8192,16384,32768")  # benches/ntt.rs:85
     ap.add_argument("--groups", default="p32,p64,n32,n64,n128")

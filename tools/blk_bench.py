@@ -48,6 +48,8 @@ def main():
     ap.add_argument("--ramp", type=float, default=1.0)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--mul", action="store_true", help="also time the fused fwd -> mul_assign_normalize -> inv call")
+    ap.add_argument("--ext", default="", help="J,O: also time the fused mul_accumulate chain (external_product_batch) against the "
+                                              "same step as separate fwd / mul_accumulate / inv calls")
     args = ap.parse_args()
     for name in args.primes.split(","):
         p = PRIMES[name]
@@ -67,6 +69,37 @@ def main():
                 print(json.dumps({"tag": args.tag, "prime": name, "n": n, "op": leg, "batch": batch, "ms": round(ms, 4),
                                   "ns_per_poly": round(ns, 2),
                                   "hbm_frac": round(words * n * 8 * batch / (ms * 1e-3) / 8e12, 4)}), flush=True)
+            if args.ext:
+                J, O = [int(x) for x in args.ext.split(",")]
+                nb = max(1, batch // (2 * J))
+                terms = torch.empty(nb * J * n, dtype=torch.int64, device="cuda")
+                key = torch.empty(J * O * n, dtype=torch.int64, device="cuda")
+                out = torch.zeros(nb * O * n, dtype=torch.int64, device="cuda")
+                cntt.fill_uniform(terms, p, 3)
+                cntt.fill_uniform(key, p, 4)
+                # the same step as separate calls, on the layout that suits THEM best: term j of every element in one plane,
+                # output o of every element in one plane, key[j][o] replicated per element (replication outside the timing)
+                planes = torch.empty(J * nb * n, dtype=torch.int64, device="cuda")
+                outp = torch.zeros(O * nb * n, dtype=torch.int64, device="cuda")
+                keyrep = [[key.view(J, O, n)[j, o].repeat(nb).contiguous() for o in range(O)] for j in range(J)]
+                tsrc = terms.view(nb, J, n).permute(1, 0, 2).contiguous().view(-1)
+
+                def separate():   # what a caller of the reference writes: fwd every term, mul_accumulate, inv every output
+                    planes.copy_(tsrc)
+                    plan.fwd_batch(planes)
+                    outp.zero_()
+                    for j in range(J):
+                        for o in range(O):
+                            plan.mul_accumulate_batch(outp[o * nb * n:(o + 1) * nb * n], planes[j * nb * n:(j + 1) * nb * n], keyrep[j][o])
+                    plan.inv_batch(outp)
+                separate()
+                sep_ms = round(timed(separate, max(2, args.reps // 3), args.ramp), 4)
+                del keyrep, planes, tsrc
+                ms = timed(lambda: plan.external_product_batch(out, terms, key, J, O, False), args.reps, args.ramp)
+                print(json.dumps({"tag": args.tag, "prime": name, "n": n, "op": "ext_J%d_O%d" % (J, O), "batch": nb, "ms": round(ms, 4),
+                                  "ns_per_element": round(ms * 1e6 / nb, 2), "separate_calls_ms": sep_ms,
+                                  "hbm_frac": round((J + O) * n * 8 * nb / (ms * 1e-3) / 8e12, 4)}), flush=True)
+                del terms, key, out, outp
             del a, plan
             torch.cuda.empty_cache()
 

@@ -22,7 +22,7 @@ cur = load(sys.argv[1])
 old = load(sys.argv[2]) if len(sys.argv) > 2 else None
 sizes = sorted({n for r in cur.values() for n in r})
 print("tools/bench_grid.py on one MI355X: the reference's bench ids (benches/ntt.rs:84-235), batched device-resident launches "
-      "with ~256 MiB operands.")
+      "with 1 GiB operands (HBM-resident: four times the 256 MiB Infinity Cache; the round-2 grid used 256 MiB).")
 print("Cell = ns per call (one polynomial) / % of 8 TB/s on the algorithmic bytes (2*N*sizeof(T) per transform, 3*N*word per "
       "negacyclic_polymul)" + ("; second line = the same cell in %s." % sys.argv[2] if old else "."))
 print()
