@@ -41,10 +41,11 @@ def pdep(x, mask):
 
 
 class Sched:
-    def __init__(self, bits, logn, inv, loge, passes, swz, block):
+    def __init__(self, bits, logn, inv, loge, passes, swz, block, pad=(0, 0)):
         self.bits, self.logn, self.inv, self.loge = bits, logn, inv, loge
         self.passes = passes  # list of (rmask, gmask)
         self.swz = swz        # list of (shift, mask, lshift) XOR terms applied to the element index
+        self.pad = pad        # (shift, words): e + (e >> shift) * words -- padded layout instead of a swizzle (family 2)
         self.tpp = 1 << (logn - loge)
         self.block = block
         self.ppb = max(1, block // self.tpp)
@@ -53,6 +54,8 @@ class Sched:
         out = e
         for sh, m, l in self.swz:
             out ^= ((e >> sh) & m) << l
+        if self.pad[1]:
+            out += (e >> self.pad[0]) * self.pad[1]
         return out
 
 
@@ -128,7 +131,14 @@ def default_swz(bits, logn, loge, passes):
 # exchanges.  The inverse is the mirror image.
 BLK_LOGN = 10
 BLK_PASSES = [(0x381, 0x380), (0x78, 0x78), (0x207, 0x7)]   # the (64, 10) forward schedule
-BLK_SWZ = [(3, 3, 1), (6, 7, 2)]                            # and its swizzle (acts inside a 1024-word block)
+# LDS layout of family 2: PADDED, e + (e >> 5) * 2 (two words behind every 32: 6.25 % more LDS, 136 KiB at N = 16384).
+# Unlike an XOR swizzle it is additive -- phys(thread part | register part) = phys(thread part) + phys(register part) -- so
+# the per-register part of every exchange address is a compile-time constant in the DS instruction's immediate offset
+# instead of one v_xor per access (-140 of 2640 VALU instructions per thread in the N = 16384 kernel; measured +2 %,
+# profiles/r03_blk_lab_ablation.txt).  Conflict score (score() below): three 2-way conflicts over the ten access sets of a
+# transform against one with the (64, 10) swizzle [(3, 3, 1), (6, 7, 2)]; found by exhaustive search over one- and two-level
+# paddings with at most 20 % overhead.
+BLK_PAD = (5, 2)
 
 
 def fam2_supported(bits, logn):
@@ -146,7 +156,7 @@ def make_sched_fam2(bits, logn, inv):
     if inv:
         passes = passes[::-1]
     tpp = 1 << (logn - 4)
-    return Sched(bits, logn, inv, 4, passes, list(BLK_SWZ), tpp)
+    return Sched(bits, logn, inv, 4, passes, [], tpp, BLK_PAD)
 
 
 def make_sched(bits, logn, inv, fam=0):
@@ -329,6 +339,7 @@ def emit(path):
                              (np_, ", ".join("0x%xu" % g for _, g in s.passes)))
                 lines.append("    static constexpr uint32_t SWZ_SH0 = %d, SWZ_M0 = 0x%xu, SWZ_L0 = %d;" % swz[0])
                 lines.append("    static constexpr uint32_t SWZ_SH1 = %d, SWZ_M1 = 0x%xu, SWZ_L1 = %d;" % swz[1])
+                lines.append("    static constexpr uint32_t PAD_SH = %d, PAD_MUL = %d;" % s.pad)
                 lines.append("};")
     lines.append("")
     with open(path, "w") as f:

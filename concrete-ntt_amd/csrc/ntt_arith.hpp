@@ -201,10 +201,13 @@ template <class T> __device__ __forceinline__ T sub_mod(T a, T b, T p) {
 // ---------------------------------------------------------------------------------------------
 template <class T, int CLS> struct Bfly {
     // forward (Cooley-Tukey): (x, y) <- (x + w y, x - w y).  UNI: w, ws are wave-uniform (scalar registers)
-    template <bool UNI = false>
+    // FIRST: the first stage of a whole transform -- x is an input coefficient, canonical by the API's contract (< p, as
+    // the reference's tests feed it: SURVEY 8(a5)), so the lazy class's conditional subtraction of 2p is a no-op and is
+    // left out (x < 2p is all the butterfly needs)
+    template <bool UNI = false, bool FIRST = false>
     static __device__ __forceinline__ void fwd(T &x, T &y, T w, T ws, const ModParams<T> &P) {
         if constexpr (CLS == CLS_LAZY) {
-            x = csub_two_p<T>(x, P.two_p, P.neg_two_p);
+            if constexpr (!FIRST) x = csub_two_p<T>(x, P.two_p, P.neg_two_p);
             if constexpr (sizeof(T) == 8) {
                 const T xn = shoup_mad<T, UNI>(y, w, ws, P.neg_p, x);  // x + t, t in [0, 2p)
                 y = ((x << 1) + P.two_p) - xn;                         // x - t + 2p
@@ -310,8 +313,8 @@ template <int CLS> struct BoxOps {
     static __device__ __forceinline__ uint64_t box(uint32_t v, const P32 &) { return box32(v); }
     static __device__ __forceinline__ uint32_t unbox(uint64_t c, const P32 &) { return (uint32_t)c; }
     // (x, y) <- (x + w y, x - w y), values in [0, 4p)
-    template <bool UNI> static __device__ __forceinline__ void fwd(uint64_t &X, uint64_t &Y, uint32_t w, uint32_t ws, const P32 &P) {
-        const uint32_t x = umin<uint32_t>((uint32_t)X, (uint32_t)X - P.two_p);
+    template <bool UNI, bool FIRST = false> static __device__ __forceinline__ void fwd(uint64_t &X, uint64_t &Y, uint32_t w, uint32_t ws, const P32 &P) {
+        const uint32_t x = FIRST ? (uint32_t)X : umin<uint32_t>((uint32_t)X, (uint32_t)X - P.two_p);   // (FIRST: see Bfly::fwd)
         const uint32_t y = (uint32_t)Y;
         const uint32_t q = __umulhi(y, ws);
         const uint64_t a = mad_box<UNI>(y, w, box32(x));
@@ -406,7 +409,7 @@ template <class T, int HEAD> struct BflyFp {
         return Fp::u(Fp::reduce(Fp::d(v), Fp::d(P.fp_p), Fp::d(P.fp_pinv)));
     }
     static __device__ __forceinline__ T pre_inverse(T v, const ModParams<T> &P) { return reduce(v, P); }  // |v| <= p
-    template <bool UNI = false>
+    template <bool UNI = false, bool FIRST = false>
     static __device__ __forceinline__ void fwd(T &x, T &y, T w, T ws, const ModParams<T> &P) {
         const double t = Fp::mul_const(Fp::d(y), Fp::d(w), Fp::d(ws), Fp::d(P.fp_p));
         const double xd = Fp::d(x);
@@ -458,7 +461,7 @@ template <> struct BoxOps<CLS_FPW> {
     static __device__ __forceinline__ uint32_t unbox(uint64_t c, const P32 &P) {
         return (uint32_t)(int32_t)Fp::reduce(Fp::d(c), Fp::d(P.fp_p), Fp::d(P.fp_pinv));   // |.| <= (p + 1) / 2 < 2^31
     }
-    template <bool UNI> static __device__ __forceinline__ void fwd(uint64_t &X, uint64_t &Y, uint32_t w, uint32_t ws, const P32 &P) {
+    template <bool UNI, bool FIRST = false> static __device__ __forceinline__ void fwd(uint64_t &X, uint64_t &Y, uint32_t w, uint32_t ws, const P32 &P) {
         const double x = Fp::d(X);
         const double t = Fp::mul_data(Fp::d(Y), tw(w, ws), Fp::d(P.fp_p), Fp::d(P.fp_pinv));
         X = Fp::u(__dadd_rn(x, t));
@@ -561,7 +564,7 @@ template <class T> struct Bfly<T, CLS_PM64> {
         const T d = x - t;
         return d - (x < t ? (T)P.pm_c : (T)0);
     }
-    template <bool UNI = false>
+    template <bool UNI = false, bool FIRST = false>
     static __device__ __forceinline__ void fwd(T &x, T &y, T w, T, const ModParams<T> &P) {
         const T t = mulc<UNI>(y, w, P);
         y = sub_c(x, t, P);

@@ -274,7 +274,7 @@ __global__ __launch_bounds__((NttBlk<T, LOGN, INV, CLS>::WPB), WPW) void ntt_ker
                                                                                      const TwPair<T> *__restrict__ tw,
                                                                                      const ModParams<T> P, uint32_t nsub) {
     using K = NttBlk<T, LOGN, INV, CLS, TWC>;
-    __shared__ __attribute__((aligned(16))) T lds[(size_t)1 << LOGN];
+    __shared__ __attribute__((aligned(16))) T lds[K::B::LDS_WORDS_1];
     K::run(data, tw, P, nsub, lds);
 }
 
@@ -314,7 +314,7 @@ struct Ntt32k {
                 for (int j = 0; j < E; ++j) {
                     a[j] = Bfly<T, CLS>::load_fix(a[j], P);
                     b[j] = Bfly<T, CLS>::load_fix(b[j], P);
-                    Bfly<T, CLS>::template fwd<true>(a[j], b[j], w14.w, w14.ws, P);
+                    Bfly<T, CLS>::template fwd<true, true>(a[j], b[j], w14.w, w14.ws, P);   // the transform's first stage
                     if constexpr (Bfly<T, CLS>::IS_FP) {  // the halves' reduction schedules assume inputs no larger than canonical ones
                         a[j] = Bfly<T, CLS>::reduce(a[j], P);
                         b[j] = Bfly<T, CLS>::reduce(b[j], P);
@@ -376,7 +376,7 @@ template <class T, bool INV, int CLS, int WPW>
 __global__ __launch_bounds__((Ntt32k<T, INV, CLS>::WPB), WPW) void ntt_kernel_32k(T *__restrict__ data, const TwPair<T> *__restrict__ tw,
                                                                                 const ModParams<T> P, uint32_t nsub) {
     using K = Ntt32k<T, INV, CLS>;
-    __shared__ __attribute__((aligned(16))) T lds[(size_t)1 << K::LOGH];
+    __shared__ __attribute__((aligned(16))) T lds[K::HB::LDS_WORDS_1];
     K::run(data, tw, P, nsub, lds);
 }
 
@@ -491,7 +491,7 @@ __global__ __launch_bounds__((MulBlk<T, LOGN, CLS>::WPB), WPW) void mul_kernel_b
                                                                                 const TwPair<T> *__restrict__ twi,
                                                                                 const ModParams<T> P, uint32_t nsub) {
     using K = MulBlk<T, LOGN, CLS, TWC, PREFETCH>;
-    __shared__ __attribute__((aligned(16))) T lds[(size_t)1 << LOGN];
+    __shared__ __attribute__((aligned(16))) T lds[K::FB::LDS_WORDS_1];
     K::run(lhs, rhs_ntt, twf, twi, P, nsub, lds);
 }
 
@@ -602,7 +602,7 @@ __global__ __launch_bounds__((ExtBlk<T, LOGN, CLS, NOUT>::WPB), WPW) void ext_ke
                                                                                    const TwPair<T> *__restrict__ twi, const ModParams<T> P,
                                                                                    uint32_t nb, uint32_t nterms, uint32_t accumulate) {
     using K = ExtBlk<T, LOGN, CLS, NOUT>;
-    __shared__ __attribute__((aligned(16))) T lds[(size_t)1 << LOGN];
+    __shared__ __attribute__((aligned(16))) T lds[K::FB::LDS_WORDS_1];
     K::run(out, terms, key_ntt, twf, twi, P, nb, nterms, accumulate != 0, lds);
 }
 

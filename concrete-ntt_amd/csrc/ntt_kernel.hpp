@@ -89,7 +89,15 @@ struct NttKernel {
     static constexpr int MAXV = 16 / (int)sizeof(T);  // elements per 16-byte access
     static constexpr size_t LDS_ELEMS = (NPASS > 1) ? ((size_t)PPB << LOGN) : 1;
 
+    // LDS layout of the exchange buffer: an XOR swizzle of the element index, or (schedule family 2) a PADDED layout
+    // e + (e >> PAD_SH) * PAD_MUL.  The padded one is additive over disjoint index bits, so gather / scatter add the
+    // register part as a compile-time constant (the DS instruction's immediate offset) to one per-thread base.
+    static constexpr bool PADDED = S::PAD_MUL != 0;
+    static_assert(!PADDED || (S::SWZ_M0 == 0 && S::SWZ_M1 == 0), "a layout is padded or swizzled");
+    static __host__ __device__ constexpr uint32_t pad_of(uint32_t e) { return e + (e >> S::PAD_SH) * S::PAD_MUL; }
+    static constexpr size_t LDS_WORDS_1 = PADDED ? (size_t)pad_of(1u << LOGN) : ((size_t)1 << LOGN);   // one polynomial
     static __device__ __forceinline__ uint32_t phys(uint32_t e) {
+        if constexpr (PADDED) return pad_of(e);
         uint32_t o = e;
         if constexpr (S::SWZ_M0 != 0) o ^= ((e >> S::SWZ_SH0) & S::SWZ_M0) << S::SWZ_L0;
         if constexpr (S::SWZ_M1 != 0) o ^= ((e >> S::SWZ_SH1) & S::SWZ_M1) << S::SWZ_L1;
@@ -119,10 +127,11 @@ struct NttKernel {
     template <uint32_t RM, class PTR> static __device__ __forceinline__ void gather(T (&r)[E], PTR base, uint32_t ebase, bool lds) {
         constexpr int NV = vec_elems<RM>();
         using V = typename VecOf<T, NV>::type;
+        const uint32_t pbase = (PADDED && lds) ? pad_of(ebase) : 0u;
 #pragma unroll
         for (int j = 0; j < E; j += NV) {
             const uint32_t e = ebase | cdep((uint32_t)j, RM);
-            const uint32_t a = lds ? phys(e) : e;
+            const uint32_t a = lds ? (PADDED ? pbase + pad_of(cdep((uint32_t)j, RM)) : phys(e)) : e;
             if constexpr (NV == 1) {
                 r[j] = base[a];
             } else {
@@ -135,10 +144,11 @@ struct NttKernel {
     template <uint32_t RM, class PTR> static __device__ __forceinline__ void scatter(const T (&r)[E], PTR base, uint32_t ebase, bool lds) {
         constexpr int NV = vec_elems<RM>();
         using V = typename VecOf<T, NV>::type;
+        const uint32_t pbase = (PADDED && lds) ? pad_of(ebase) : 0u;
 #pragma unroll
         for (int j = 0; j < E; j += NV) {
             const uint32_t e = ebase | cdep((uint32_t)j, RM);
-            const uint32_t a = lds ? phys(e) : e;
+            const uint32_t a = lds ? (PADDED ? pbase + pad_of(cdep((uint32_t)j, RM)) : phys(e)) : e;
             if constexpr (NV == 1) {
                 base[a] = r[j];
             } else {
@@ -360,6 +370,7 @@ struct NttKernel {
     static __device__ __forceinline__ void stage_butterflies(R (&r)[E], const TwPair<T> (&w)[CH], int h0, const ModParams<T> &P) {
         constexpr uint32_t RM = S::RMASK[K], GM = S::GMASK[K];
         constexpr int b = nth_stage_bit(GM, GI), k = crank(RM, b);
+        constexpr bool FIRST = !INV && !SUB && stage_no(K, GI) == 0;   // inputs of a whole forward transform: canonical (Bfly::fwd)
 #pragma unroll
         for (int j = 0; j < E; ++j) {
             if ((j >> k) & 1) continue;
@@ -369,11 +380,11 @@ struct NttKernel {
             // sub-block kernels: their table prefix depends on the polynomial a thread works on)
             if constexpr (!std::is_same<R, T>::value) {
                 if constexpr (INV) BoxOps<CLS>::template inv<UNI>(r[j], r[j | (1 << k)], w[h - h0].w, w[h - h0].ws, P);
-                else BoxOps<CLS>::template fwd<UNI>(r[j], r[j | (1 << k)], w[h - h0].w, w[h - h0].ws, P);
+                else BoxOps<CLS>::template fwd<UNI, FIRST>(r[j], r[j | (1 << k)], w[h - h0].w, w[h - h0].ws, P);
             } else if constexpr (INV)
                 Bfly<T, CLS>::template inv<UNI>(r[j], r[j | (1 << k)], w[h - h0].w, w[h - h0].ws, P);
             else
-                Bfly<T, CLS>::template fwd<UNI>(r[j], r[j | (1 << k)], w[h - h0].w, w[h - h0].ws, P);
+                Bfly<T, CLS>::template fwd<UNI, FIRST>(r[j], r[j | (1 << k)], w[h - h0].w, w[h - h0].ws, P);
         }
     }
 
@@ -413,6 +424,7 @@ struct NttKernel {
         constexpr bool WAVE_UNI = FAM == 2 && !g.uniform && g.shift >= 6 && TPP >= 64;
         if constexpr (WAVE_UNI || (FAM == 2 && SUB && g.uniform)) toff = (uint32_t)__builtin_amdgcn_readfirstlane((int)toff);
         constexpr bool UNI = (g.uniform && (!SUB || FAM == 2)) || WAVE_UNI;
+        constexpr bool FIRST = !INV && !SUB && stage_no(K, GI) == 0;   // inputs of a whole forward transform: canonical (Bfly::fwd)
         constexpr bool CHUNKED = TWC > 0 && !UNI && NHI > TWC;
         constexpr int CH = CHUNKED ? TWC : NHI;
         if constexpr (CHUNKED && FAM == 2) {
@@ -457,11 +469,11 @@ struct NttKernel {
                     // sub-block kernels: their table prefix depends on the polynomial a thread works on)
                     if constexpr (!std::is_same<R, T>::value) {
                         if constexpr (INV) BoxOps<CLS>::template inv<UNI>(r[j], r[j | (1 << k)], w[h - h0].w, w[h - h0].ws, P);
-                        else BoxOps<CLS>::template fwd<UNI>(r[j], r[j | (1 << k)], w[h - h0].w, w[h - h0].ws, P);
+                        else BoxOps<CLS>::template fwd<UNI, FIRST>(r[j], r[j | (1 << k)], w[h - h0].w, w[h - h0].ws, P);
                     } else if constexpr (INV)
                         Bfly<T, CLS>::template inv<UNI>(r[j], r[j | (1 << k)], w[h - h0].w, w[h - h0].ws, P);
                     else
-                        Bfly<T, CLS>::template fwd<UNI>(r[j], r[j | (1 << k)], w[h - h0].w, w[h - h0].ws, P);
+                        Bfly<T, CLS>::template fwd<UNI, FIRST>(r[j], r[j | (1 << k)], w[h - h0].w, w[h - h0].ws, P);
                 }
                 if constexpr (CHUNKED) __builtin_amdgcn_sched_barrier(0);  // keep the chunks (and their registers) apart
             }

@@ -57,7 +57,7 @@ static hipError_t launch_one(T *data, const TwPair<T> *tw, const ModParams<T> &P
     if constexpr (blk_eligible<T, LOGN, INV, CLS, SUB>()) {
         if (blk_enabled()) {
             using W = NttBlk<T, LOGN, INV, CLS>;
-            constexpr size_t LDS_BYTES = sizeof(T) << LOGN;
+            constexpr size_t LDS_BYTES = sizeof(T) * W::B::LDS_WORDS_1;
             constexpr int BY_LDS = (int)((160 * 1024) / LDS_BYTES), BY_WAVES = 16 / (W::WPB / 64);
             constexpr int BPC = BY_LDS < BY_WAVES ? BY_LDS : BY_WAVES;
             uint32_t grid = (uint32_t)num_cus() * BPC;

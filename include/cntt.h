@@ -19,6 +19,10 @@
  *       CNTT_ELEN     the reference's assert_eq!(buf.len(), ntt_size) fails (src/prime64.rs:795,873)
  *       CNTT_EDEVICE  HIP error (no GPU, launch or copy failure) -- there is NO CPU fallback
  *       CNTT_ENOMEM   allocation failure
+ *   - input contract of the transforms: coefficients are canonical, 0 <= x < modulus -- what the reference's tests feed
+ *     (src/prime64.rs:1234-1252) and the only range on which its back ends agree with each other.  The
+ *     kernels use it (the lazy classes skip the first stage's conditional subtraction); larger words give unspecified
+ *     residues, as they do in the reference.  Every output is canonical.
  *   - host-slice calls (no _batch suffix) mirror the Rust methods one to one: data is copied to the
  *     current HIP device, transformed by the HIP kernels, and copied back, synchronously.
  *   - _batch calls are the measured path: `batch` polynomials stored back to back (polynomial b at

@@ -41,10 +41,7 @@ def operands(line):
 def check_kernel(name, insts):
     """insts: [(address, text)] in layout order.  From every vector-memory load, walk forward until the s_waitcnt that
     retires it (vmcnt(N) leaves only the N youngest operations in flight) and require that nothing on the way touches
-    its destination registers.  Two walks per load cover both loop layouts hipcc produces for the persistent kernels:
-    conditional branches never taken, and backward conditional branches taken when they land on a wait (the prefetch's
-    wait opens the loop latch, which may precede the loop body; the other backward branch of that layout re-tests the
-    condition that guarded the prefetch and leaves the loop); unconditional branches are followed in both."""
+    its destination registers (the walk's branch rule is described at the loop below)."""
     index = {a: k for k, (a, _) in enumerate(insts)}
     parsed = []
     for addr, ln in insts:
@@ -65,29 +62,33 @@ def check_kernel(name, insts):
         if not (op0.startswith(VMEM) and "load" in op0 and not op0.startswith("scratch")):
             continue
         loads += 1
-        for take_backward in (False, True):
-            k, younger, steps = k0 + 1, 0, 0
-            while k < len(parsed) and steps < 40000:
-                steps += 1
-                op, touched, target, keep, _ = parsed[k]
-                if k == k0 or op == "s_endpgm":
-                    break
-                if keep is not None:
-                    if younger >= keep:
-                        break           # retired
-                elif target is not None:
-                    latch = any(parsed[t][3] is not None for t in range(target, min(target + 2, len(parsed))))
-                    if op == "s_branch" or (take_backward and target <= k and latch):
-                        k = target
-                        continue
-                else:
-                    if op.startswith(VMEM) and "load" in op:
-                        touched = touched - parsed[k][4]   # a younger load may overwrite it: loads return in order
-                    assert not (touched & dst), "%s: `%s` touches v%s of `%s` still in flight" % (
-                        name, insts[k][1], sorted(touched & dst), insts[k0][1])
-                    if op.startswith(VMEM):
-                        younger += 1
-                k += 1
+        # One walk per load.  Unconditional branches are followed; a conditional branch is taken exactly when it lands on
+        # a wait (the loop latch hipcc builds for `if (more) { wait; unpack }`: the branch condition is the one that
+        # guarded the prefetch, so for a load that WAS issued the taken side is the only feasible one -- falling through
+        # it would walk the iteration that issued no prefetch and may legitimately reuse the registers); every other
+        # conditional branch is not taken (forward skips around code that is not on the prefetch's path).
+        k, younger, steps = k0 + 1, 0, 0
+        while k < len(parsed) and steps < 40000:
+            steps += 1
+            op, touched, target, keep, _ = parsed[k]
+            if k == k0 or op == "s_endpgm":
+                break
+            if keep is not None:
+                if younger >= keep:
+                    break           # retired
+            elif target is not None:
+                latch = any(parsed[t][3] is not None for t in range(target, min(target + 2, len(parsed))))
+                if op == "s_branch" or latch:
+                    k = target
+                    continue
+            else:
+                if op.startswith(VMEM) and "load" in op:
+                    touched = touched - parsed[k][4]   # a younger load may overwrite it: loads return in order
+                assert not (touched & dst), "%s: `%s` touches v%s of `%s` still in flight" % (
+                    name, insts[k][1], sorted(touched & dst), insts[k0][1])
+                if op.startswith(VMEM):
+                    younger += 1
+            k += 1
     return loads
 
 

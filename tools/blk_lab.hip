@@ -50,7 +50,7 @@ template <int LOGN, bool INV, int WPW, int TWC>
 __global__ __launch_bounds__((NttBlk<uint64_t, LOGN, INV, LAB_CLS>::WPB), WPW) void lab_blk(uint64_t *data, const TwPair<uint64_t> *tw,
                                                                                           const ModParams<uint64_t> P, uint32_t nsub) {
     using K = NttBlk<uint64_t, LOGN, INV, LAB_CLS, TWC>;
-    __shared__ __attribute__((aligned(16))) uint64_t lds[(size_t)1 << LOGN];
+    __shared__ __attribute__((aligned(16))) uint64_t lds[K::B::LDS_WORDS_1];
 #ifdef LAB_STAMPS
     if (threadIdx.x < 16) {
         lab_prev[threadIdx.x] = 0;
