@@ -87,7 +87,6 @@ struct NttKernel {
     static constexpr uint32_t FULL = (LOGN >= 32) ? 0xffffffffu : ((1u << LOGN) - 1u);
     static constexpr bool WAVE_PRIVATE = TPP <= 64;  // a polynomial never spans two wavefronts
     static constexpr int MAXV = 16 / (int)sizeof(T);  // elements per 16-byte access
-    static constexpr size_t LDS_ELEMS = (NPASS > 1) ? ((size_t)PPB << LOGN) : 1;
 
     // LDS layout of the exchange buffer: an XOR swizzle of the element index, or (schedule family 2) a PADDED layout
     // e + (e >> PAD_SH) * PAD_MUL.  The padded one is additive over disjoint index bits, so gather / scatter add the
@@ -96,6 +95,7 @@ struct NttKernel {
     static_assert(!PADDED || (S::SWZ_M0 == 0 && S::SWZ_M1 == 0), "a layout is padded or swizzled");
     static __host__ __device__ constexpr uint32_t pad_of(uint32_t e) { return e + (e >> S::PAD_SH) * S::PAD_MUL; }
     static constexpr size_t LDS_WORDS_1 = PADDED ? (size_t)pad_of(1u << LOGN) : ((size_t)1 << LOGN);   // one polynomial
+    static constexpr size_t LDS_ELEMS = (NPASS > 1) ? (size_t)PPB * LDS_WORDS_1 : 1;
     static __device__ __forceinline__ uint32_t phys(uint32_t e) {
         if constexpr (PADDED) return pad_of(e);
         uint32_t o = e;
@@ -555,7 +555,7 @@ struct NttKernel {
         const uint32_t sub = blockIdx.x * PPB + pl;
         const bool active = sub < nsub;
         T *g = data + ((size_t)sub << LOGN);
-        T *lds = lds_all + ((size_t)pl << LOGN);
+        T *lds = lds_all + (size_t)pl * LDS_WORDS_1;
         uint32_t qpre = 0;
         if constexpr (SUB) qpre = (sub & ((1u << depth) - 1u)) << LOGN;
         T r[E];
@@ -698,7 +698,7 @@ struct NttWp : NttKernel<T, LOGN, INV, CLS, false, FAM> {
         }
         const uint32_t tid = threadIdx.x & (TPP - 1);
         const uint32_t pl = threadIdx.x / TPP;
-        T *lds = lds_all + ((size_t)pl << LOGN);
+        T *lds = lds_all + (size_t)pl * B::LDS_WORDS_1;
         constexpr uint32_t RM0 = S::RMASK[0], CM0 = FULL & ~RM0;
         constexpr uint32_t RML = S::RMASK[NPASS - 1], CML = FULL & ~RML;
         constexpr uint32_t CMIO = FULL & ~IO_RM;
@@ -777,7 +777,7 @@ template <class T, int LOGN, bool INV, int CLS, int WPB, int WPW>
 __global__ __launch_bounds__(WPB, WPW) void ntt_kernel_wp(T *__restrict__ data, const TwPair<T> *__restrict__ tw,
                                                       const ModParams<T> P, uint32_t nsub) {
     using K = NttWp<T, LOGN, INV, CLS, WPB>;
-    __shared__ __attribute__((aligned(16))) T lds[(size_t)K::PPB << LOGN];
+    __shared__ __attribute__((aligned(16))) T lds[(size_t)K::PPB * K::B::LDS_WORDS_1];
     __shared__ __attribute__((aligned(16))) TwPair<T> img[K::B::IMG_ENTRIES];
     K::run(data, tw, P, nsub, lds, img);
 }
@@ -811,7 +811,7 @@ struct MulWp {
         __syncthreads();
         const uint32_t tid = threadIdx.x & (TPP - 1);
         const uint32_t pl = threadIdx.x / TPP;
-        T *lds = lds_all + ((size_t)pl << LOGN);
+        T *lds = lds_all + (size_t)pl * FB::LDS_WORDS_1;
         constexpr uint32_t CM0 = FULL & ~RM0, CMM = FULL & ~RMM, CML = FULL & ~RML, CMIO = FULL & ~IO_RM;
         const uint32_t ebase0 = pdep<CM0>(tid), ebaseM = pdep<CMM>(tid), ebaseL = pdep<CML>(tid), ebaseIO = pdep<CMIO>(tid);
         const uint32_t ntiles = (nsub + PPB - 1) / PPB;
@@ -886,7 +886,7 @@ __global__ __launch_bounds__(WPB, WPW) void mul_kernel_wp(T *__restrict__ lhs, c
                                                       const TwPair<T> *__restrict__ twi, const ModParams<T> P,
                                                       uint32_t nsub) {
     using K = MulWp<T, LOGN, CLS, WPB>;
-    __shared__ __attribute__((aligned(16))) T lds[(size_t)K::PPB << LOGN];
+    __shared__ __attribute__((aligned(16))) T lds[(size_t)K::PPB * K::FB::LDS_WORDS_1];
     __shared__ __attribute__((aligned(16))) TwPair<T> imgf[K::FB::IMG_ENTRIES];
     __shared__ __attribute__((aligned(16))) TwPair<T> imgi[K::IB::IMG_ENTRIES];
     K::run(lhs, rhs_ntt, twf, twi, P, nsub, lds, imgf, imgi);
@@ -953,7 +953,7 @@ struct ExtWp {
         __syncthreads();
         const uint32_t tid = threadIdx.x & (TPP - 1);
         const uint32_t pl = threadIdx.x / TPP;
-        T *lds = lds_all + ((size_t)pl << LOGN);
+        T *lds = lds_all + (size_t)pl * FB::LDS_WORDS_1;
         constexpr uint32_t CM0 = FULL & ~RM0, CMM = FULL & ~RMM, CML = FULL & ~RML, CMIO = FULL & ~IO_RM;
         const uint32_t ebase0 = pdep<CM0>(tid), ebaseM = pdep<CMM>(tid), ebaseL = pdep<CML>(tid), ebaseIO = pdep<CMIO>(tid);
         const uint32_t ntiles = (nb + PPB - 1) / PPB;
@@ -1030,7 +1030,7 @@ __global__ __launch_bounds__(WPB, WPW) void ext_kernel_wp(T *__restrict__ out, c
                                                       const TwPair<T> *__restrict__ twi, const ModParams<T> P,
                                                       uint32_t nb, uint32_t nterms, uint32_t accumulate) {
     using K = ExtWp<T, LOGN, CLS, WPB, NOUT>;
-    __shared__ __attribute__((aligned(16))) T lds[(size_t)K::PPB << LOGN];
+    __shared__ __attribute__((aligned(16))) T lds[(size_t)K::PPB * K::FB::LDS_WORDS_1];
     __shared__ __attribute__((aligned(16))) TwPair<T> imgf[K::FB::IMG_ENTRIES];
     __shared__ __attribute__((aligned(16))) TwPair<T> imgi[K::IB::IMG_ENTRIES];
     K::run(out, terms, key_ntt, twf, twi, P, nb, nterms, accumulate != 0, lds, imgf, imgi);

@@ -16,7 +16,7 @@ template <class T, int LOGN> struct MulShape {
     using K0 = NttKernel<T, LOGN, false, CLS_LAZY, false>;
     static constexpr size_t IMG = (size_t)K0::IMG_ENTRIES * sizeof(TwPair<T>);
     static constexpr size_t LDS_MAX = 160 * 1024;
-    static constexpr size_t lds(int block) { return (size_t)block * K0::E * sizeof(T) + 2 * IMG; }
+    static constexpr size_t lds(int block) { return (size_t)(block / K0::TPP) * K0::LDS_WORDS_1 * sizeof(T) + 2 * IMG; }
     static constexpr bool THREE_SMALL = 3 * lds(256) <= LDS_MAX && K0::E == 16;
     static constexpr bool ONE_BIG = !THREE_SMALL && lds(768) <= LDS_MAX && K0::E == 16 && K0::TPP <= 256 && 768 % K0::TPP == 0;
     static constexpr bool TWO_SMALL = 2 * lds(256) <= LDS_MAX;

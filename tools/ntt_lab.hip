@@ -82,7 +82,7 @@ template <bool INV> __global__ __launch_bounds__(256) void lab_alu_only(uint64_t
 template <bool INV, int WPB, int WPW, int TWC = 0> __global__ __launch_bounds__(WPB, WPW) void lab_wp_stamped(
     uint64_t *data, const TwPair<uint64_t> *tw, const ModParams<uint64_t> P, uint32_t nsub) {
     using K = NttWp<uint64_t, 10, INV, CLS_LAZY, WPB>;
-    __shared__ __attribute__((aligned(16))) uint64_t lds[(size_t)K::PPB << 10];
+    __shared__ __attribute__((aligned(16))) uint64_t lds[(size_t)K::PPB * K::B::LDS_WORDS_1];
     __shared__ __attribute__((aligned(16))) TwPair<uint64_t> img[K::B::IMG_ENTRIES];
     LabStamp st;
     st.begin();

@@ -78,7 +78,8 @@ def prod_plan(n, primes, batch):
 if __name__ == "__main__":
     prime(prime64, 64, 1024, P62, 65536)       # C2: mul_kernel_wp / ntt_kernel_wp / pointwise_kernel
     prime(prime64, 64, 16384, P62, 4096)       # C4 kernel: ntt_kernel_blk<u64, 14>
-    prime(prime64, 64, 4096, P62, 16384)
+    prime(prime64, 64, 4096, P62, 16384)       # ntt_kernel_blk<u64, 12>, mul_kernel_blk
+    prime(prime64, 64, 32768, P62, 2048)       # ntt_kernel_32k (single pass over HBM)
     prime(prime64, 64, 1024, P50, 65536)       # CLS_FP
     prime(prime64, 64, 1024, P51, 65536)       # CLS_FP51
     prime(prime64, 64, 1024, SOLINAS, 65536)   # generic class
@@ -87,4 +88,5 @@ if __name__ == "__main__":
     native(native_binary64.Plan32, 2048, 65536, True)    # C5
     native(native64.Plan32, 8192, 4096, False)           # native_polymul_kernel_g (persistent, global parking)
     chain(1024, P62, 6, 2, 8192)                          # ext_kernel_wp
+    chain(4096, P62, 6, 2, 2048)                          # ext_kernel_blk
     prod_plan(2048, [4294955009, 4294914049], 32768)      # product_fused
