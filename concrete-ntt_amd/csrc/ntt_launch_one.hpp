@@ -33,10 +33,10 @@ template <class K> static constexpr bool wp_eligible() {
 // Wave-block kernel (ntt_blk.hpp): 64-bit words, N = 4096 ... 16384, every class but the Montgomery one.
 // BLK_TWC: twiddle pairs a thread loads at a time in the block passes -- what fits 128 VGPRs without spilling
 // (tests/test_host_plan.py and tests/test_async_load_guard.py check the code objects).
-// Not instantiated: the inverse of the strict class at N >= 8192 (hipcc, ROCm 7.2, cannot fit it into 128 VGPRs without
-// spilling, and a spilled register must never meet the asynchronous prefetch; it stays on ntt_kernel).
+// (The inverse of the strict class at N >= 8192 spilled at 128 VGPRs until the padded exchange layout freed the swizzle's
+// address registers: 112 VGPRs now, instantiated like the rest.)
 template <class T, int LOGN, bool INV, int CLS, bool SUB> static constexpr bool blk_eligible() {
-    return sizeof(T) == 8 && !SUB && LOGN >= 12 && LOGN <= 14 && CLS != CLS_GENERIC && !(INV && CLS == CLS_STRICT && LOGN >= 13);
+    return sizeof(T) == 8 && !SUB && LOGN >= 12 && LOGN <= 14 && CLS != CLS_GENERIC;
 }
 // (double-buffered: 2 * TWC pairs are in flight; the forward kernels hold the prefetch across these passes, the inverse ones
 // issue it behind them)

@@ -55,7 +55,7 @@ constexpr bool mul_blk_eligible(int bytes, int logn, int cls) { return bytes == 
 template <int LOGN, int CLS> struct MulBlkShape {
     static constexpr int WPW = 4;
     static constexpr int PER_CU = LOGN == 12 ? 4 : LOGN == 13 ? 2 : 1;
-    static constexpr bool PREFETCH = !(CLS == CLS_STRICT && LOGN != 13);   // (the strict class spills 2-4 registers with it there)
+    static constexpr bool PREFETCH = true;
     static constexpr int TWC = 1;
 };
 template <class T, int LOGN, int CLS>

@@ -172,7 +172,7 @@ def test_prefetch_overlaps_the_butterflies(tmp_path):
     seen = 0
     for name, body in persistent_kernels(tmp_path):
         if re.search(r"mul_kernel_blk.*Lb0EEEv", name):
-            continue    # <..., PREFETCH = false>: the one shape compiled without the register prefetch (ntt_mul_one.hpp)
+            continue    # <..., PREFETCH = false>: a shape compiled without the register prefetch (none at present, ntt_mul_one.hpp)
         best, total = prefetch_distance(body)
         assert best >= 0.15 * total, "%s: the prefetch is retired after %d of %d VALU instructions" % (name, best, total)
         seen += 1
