@@ -416,7 +416,10 @@ template <class T> static int mul_ntt_device(const PrimePlan<T> *pl, T *lhs, con
     if (batch >= ((size_t)1 << 32)) return fail(CNTT_EINVAL, "batch too large for one launch");
     DeviceTables<T> t;
     if (int rc = device_tables(pl, &t)) return rc;
-    const int tcls = transform_class(pl);
+    int tcls = transform_class(pl);
+    // one size past the LDS-resident ones (64-bit words): the single-pass kernels run in the plan's 64-bit-only class where
+    // it has one, like ntt_device
+    if (sizeof(T) == 8 && pl->logn == MaxLdsLogN<T>::value + 1) tcls = pl->mp.fp ? (int)pl->mp.fp : pl->mp.pm_c ? (int)CLS_PM64 : tcls;
     const hipError_t e = launch_mul_ntt<T>(pl->logn, tcls, lhs, rhs, alt_tables(tcls) ? t.fwd_fp : t.fwd,
                                            alt_tables(tcls) ? t.inv_fp : t.inv, pl->mp, (uint32_t)batch, st);
     if (e == hipSuccess) return CNTT_OK;

@@ -496,6 +496,114 @@ __global__ __launch_bounds__((MulBlk<T, LOGN, CLS>::WPB), WPW) void mul_kernel_b
 }
 
 // -------------------------------------------------------------------------------------------------
+// The fused product at N = 32768 (Ntt32k's counterpart of MulBlk): one pass over HBM for
+//     lhs <- inv( mul_assign_normalize( fwd(lhs), rhs_ntt ) ).
+// The stage on index bit 14 in registers, then each 16384-point half in turn -- forward walk, products against the matching
+// half of rhs_ntt in the wavefronts' block layout, inverse walk -- while the other half is parked in registers; the inverse
+// stage on bit 14 is the transform's last one and carries 1/N (Bfly::inv_norm).  3 N words of HBM traffic instead of 7 N.
+// Ordinary loads (no asynchronous prefetch: the parked half takes its place).
+// -------------------------------------------------------------------------------------------------
+template <class T, int CLS, int TWC = 1>
+struct Mul32k {
+    static constexpr int LOGH = 14;
+    using HF = NttBlk<T, LOGH, false, CLS, TWC, true>;
+    using HI = NttBlk<T, LOGH, true, CLS, TWC, true>;
+    using HB = typename HF::B;
+    static constexpr int E = HF::E, WPB = HF::WPB;
+    static constexpr uint32_t FULL = HF::FULL, TOP = HF::RM0, RMM = HF::RM3;
+    static_assert(RMM == HI::RM0 && TOP == HI::RM3, "forward and inverse schedules must mirror each other");
+
+    // one half, past the forward stage on bit 14: forward walk, products, inverse walk up to (not including) that stage
+    static __device__ __forceinline__ void half(T (&r)[E], T *lds, uint32_t tidv, const T *__restrict__ rhs_half,
+                                                const TwPair<T> *__restrict__ twf, const TwPair<T> *__restrict__ twi,
+                                                const ModParams<T> &P, uint32_t qpre) {
+        HF::template transform<false>(r, lds, tidv, twf, P, typename HF::NoHook{}, qpre);
+        if constexpr (!Bfly<T, CLS>::FUSED_LAZY) {
+#pragma unroll
+            for (int j = 0; j < E; ++j) r[j] = Bfly<T, CLS>::finish_fwd(r[j], P);
+        }
+        {   // rhs_ntt four coefficients at a time, phases pinned (see MulBlk)
+            constexpr int CH = 4, NCH = E / CH;
+            const uint32_t roff = pdep<FULL & ~RMM>(tidv) * (uint32_t)sizeof(T);
+#pragma unroll
+            for (int j = 0; j < E; ++j) asm volatile("" : "+v"(r[j]));
+            T bc[2][CH];
+            asm volatile("" ::: "memory");
+            HB::template gather_tile_part<RMM, 0, CH>(bc[0], rhs_half, roff);
+            static_for<0, NCH>([&](auto c) {
+                constexpr int C = decltype(c)::value;
+                asm volatile("" ::: "memory");
+                if constexpr (C + 1 < NCH) HB::template gather_tile_part<RMM, (C + 1) * CH, CH>(bc[(C + 1) & 1], rhs_half, roff);
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int i = 0; i < CH; ++i) {
+                    r[C * CH + i] = mul_for_inv<T, CLS>(r[C * CH + i], bc[C & 1][i], P);
+                    asm volatile("" : "+v"(r[C * CH + i]));
+                }
+            });
+        }
+        uint32_t ti = tidv;   // fresh opaque copy: no address of the forward walk stays live into the inverse walk
+        asm volatile("" : "+v"(ti));
+        HI::template transform<false>(r, lds, ti, twi, P, typename HI::NoHook{}, qpre);
+    }
+
+    static __device__ __forceinline__ void run(T *__restrict__ lhs, const T *__restrict__ rhs_ntt,
+                                               const TwPair<T> *__restrict__ twf, const TwPair<T> *__restrict__ twi,
+                                               const ModParams<T> &P, uint32_t nsub, T *lds) {
+        constexpr uint32_t CMT = FULL & ~TOP;
+        const uint32_t tid = threadIdx.x;
+        const TwPair<T> w14 = twf[1];   // forward stage on bit 14 (the inverse one rides in Bfly::inv_norm: P.last_w)
+        for (uint32_t tile = blockIdx.x; tile < nsub; tile += gridDim.x) {
+            uint32_t tidv = tid;
+            asm volatile("" : "+v"(tidv));
+            T *base = lhs + ((size_t)tile << (LOGH + 1));
+            const T *rb = rhs_ntt + ((size_t)tile << (LOGH + 1));
+            T a[E], b[E];
+            HB::template gather_tile<TOP>(a, (const T *)base, pdep<CMT>(tidv) * (uint32_t)sizeof(T));
+            HB::template gather_tile<TOP>(b, (const T *)(base + ((size_t)1 << LOGH)), pdep<CMT>(tidv) * (uint32_t)sizeof(T));
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                a[j] = Bfly<T, CLS>::load_fix(a[j], P);
+                b[j] = Bfly<T, CLS>::load_fix(b[j], P);
+                Bfly<T, CLS>::template fwd<true, true>(a[j], b[j], w14.w, w14.ws, P);
+                if constexpr (Bfly<T, CLS>::IS_FP) {  // the halves' reduction schedules assume inputs no larger than canonical ones
+                    a[j] = Bfly<T, CLS>::reduce(a[j], P);
+                    b[j] = Bfly<T, CLS>::reduce(b[j], P);
+                }
+            }
+            uint32_t t2 = tidv;
+            asm volatile("" : "+v"(t2));
+            half(a, lds, tidv, rb, twf, twi, P, 0u);
+            half(b, lds, t2, rb + ((size_t)1 << LOGH), twf, twi, P, 1u << LOGH);
+            uint32_t t3 = tid;
+            asm volatile("" : "+v"(t3));
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                if constexpr (Bfly<T, CLS>::IS_FP) {  // whatever the halves' schedules left: back to |v| <= p/2 before the last stage
+                    a[j] = Bfly<T, CLS>::reduce(a[j], P);
+                    b[j] = Bfly<T, CLS>::reduce(b[j], P);
+                }
+                Bfly<T, CLS>::inv_norm(a[j], b[j], P);
+                a[j] = Bfly<T, CLS>::finish_inv(a[j], P);
+                b[j] = Bfly<T, CLS>::finish_inv(b[j], P);
+            }
+            HB::template scatter_tile<TOP>(a, base, pdep<CMT>(t3) * (uint32_t)sizeof(T));
+            HB::template scatter_tile<TOP>(b, base + ((size_t)1 << LOGH), pdep<CMT>(t3) * (uint32_t)sizeof(T));
+        }
+    }
+};
+
+template <class T, int CLS, int WPW>
+__global__ __launch_bounds__((Mul32k<T, CLS>::WPB), WPW) void mul_kernel_32k(T *__restrict__ lhs, const T *__restrict__ rhs_ntt,
+                                                                         const TwPair<T> *__restrict__ twf,
+                                                                         const TwPair<T> *__restrict__ twi, const ModParams<T> P,
+                                                                         uint32_t nsub) {
+    using K = Mul32k<T, CLS>;
+    __shared__ __attribute__((aligned(16))) T lds[K::HB::LDS_WORDS_1];
+    K::run(lhs, rhs_ntt, twf, twi, P, nsub, lds);
+}
+
+// -------------------------------------------------------------------------------------------------
 // Fused mul_accumulate chain on the wave-block walk (the large-N counterpart of ExtWp, ntt_kernel.hpp):
 //     for each o < NOUT:  out[b][o] (+)= inv( sum_{j < J} fwd(terms[b][j]) (.) key_ntt[j][o] )
 // i.e. the caller's  for j { plan.fwd(t_j); for o { plan.mul_accumulate(acc_o, t_j, key[j][o]) } }  for o { plan.inv(acc_o) }

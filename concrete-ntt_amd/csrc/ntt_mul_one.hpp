@@ -70,4 +70,14 @@ static hipError_t mul_blk_one(T *lhs, const T *rhs, const TwPair<T> *twf, const 
     return hipGetLastError();
 }
 
+// N = 32768, 64-bit words: Mul32k (ntt_blk.hpp), one 1024-thread workgroup per CU
+template <class T, int CLS>
+static hipError_t mul_32k_one(T *lhs, const T *rhs, const TwPair<T> *twf, const TwPair<T> *twi, const ModParams<T> &P,
+                              uint32_t nsub, hipStream_t stream) {
+    uint32_t grid = (uint32_t)mul_num_cus();
+    if (grid > nsub) grid = nsub;
+    hipLaunchKernelGGL((mul_kernel_32k<T, CLS, 4>), dim3(grid), dim3(Mul32k<T, CLS>::WPB), 0, stream, lhs, rhs, twf, twi, P, nsub);
+    return hipGetLastError();
+}
+
 }  // namespace cntt

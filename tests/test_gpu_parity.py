@@ -267,13 +267,15 @@ P50, P51, P63, SOLINAS, PM64 = 1125899904679937, 2251799813554177, 9223372036853
 
 @pytest.mark.parametrize("n,p", [(4096, P62), (8192, P62), (16384, P62), (4096, P50), (8192, P50), (16384, P50), (4096, P51),
                                  (16384, P51), (4096, P63), (8192, P63), (16384, P63), (4096, SOLINAS), (8192, PM64),
-                                 (16384, SOLINAS), (16384, PM64)])
+                                 (16384, SOLINAS), (16384, PM64), (32768, P62), (32768, P50), (32768, P51), (32768, P63),
+                                 (32768, SOLINAS), (32768, PM64)])
 def test_fused_mul_ntt_large_sizes(oracle, plans, oplans, n, p):
-    """The fused product on the wave-block walk (mul_kernel_blk, u64 n = 4096 ... 16384, every class but the Montgomery one,
-    which keeps the three launches): same values as fwd; mul_assign_normalize; inv of the oracle -- with more polynomials
-    than resident workgroups (several trips round the persistent loop, prefetch included) and ragged batch sizes."""
+    """The fused product on the wave-block walk (mul_kernel_blk, u64 n = 4096 ... 16384; mul_kernel_32k at n = 32768: one
+    register stage around two half walks; every class but the Montgomery one, which keeps the three launches): same values
+    as fwd; mul_assign_normalize; inv of the oracle -- with more polynomials than resident workgroups (several trips round
+    the persistent loop, prefetch included) and ragged batch sizes."""
     plan, ref = plans(64, n, p), oplans(64, n, p)
-    for batch in (1, 5, 1100 if n == 4096 else 530 if n == 8192 else 270):
+    for batch in (1, 5, 1100 if n == 4096 else 530 if n == 8192 else 270 if n == 16384 else 260):
         a = oracle.fill_uniform(batch * n, p, 131 + batch, 64)
         b = oracle.fill_uniform(batch * n, p, 197 + batch, 64)
         want, bn = a.copy(), b.copy()
