@@ -36,7 +36,7 @@ def test_gpu_random_plans(oracle, seed):
     bits = 64 if seed % 2 == 0 else 32
     mod = prime64 if bits == 64 else prime32
     dt = np.uint64 if bits == 64 else np.uint32
-    logn = rng.randint(4 if bits == 64 else 5, 13)
+    logn = rng.randint(4 if bits == 64 else 5, 15)
     n = 1 << logn
     p = _random_prime(oracle, rng, bits, n, top=seed % 3 == 0)
     plan, oplan = mod.Plan.try_new(n, p), oracle.Plan.try_new(n, p, bits)
