@@ -909,10 +909,10 @@ template <int I, int N, class F> __device__ __forceinline__ void static_for(F &&
     }
 }
 
-template <class T, int LOGN, int CLS, int WPB, int NOUT>
+template <class T, int LOGN, int CLS, int WPB, int NOUT, int FAM = 0>
 struct ExtWp {
-    using F = NttWp<T, LOGN, false, CLS, WPB>;
-    using I = NttWp<T, LOGN, true, CLS, WPB>;
+    using F = NttWp<T, LOGN, false, CLS, WPB, FAM>;
+    using I = NttWp<T, LOGN, true, CLS, WPB, FAM>;
     using FB = typename F::B;
     using IB = typename I::B;
     static constexpr int E = FB::E, TPP = FB::TPP, NPASS = FB::NPASS, PPB = WPB / TPP;
@@ -1024,12 +1024,12 @@ struct ExtWp {
     }
 };
 
-template <class T, int LOGN, int CLS, int WPB, int WPW, int NOUT>
+template <class T, int LOGN, int CLS, int WPB, int WPW, int NOUT, int FAM = 0>
 __global__ __launch_bounds__(WPB, WPW) void ext_kernel_wp(T *__restrict__ out, const T *__restrict__ terms,
                                                       const T *__restrict__ key_ntt, const TwPair<T> *__restrict__ twf,
                                                       const TwPair<T> *__restrict__ twi, const ModParams<T> P,
                                                       uint32_t nb, uint32_t nterms, uint32_t accumulate) {
-    using K = ExtWp<T, LOGN, CLS, WPB, NOUT>;
+    using K = ExtWp<T, LOGN, CLS, WPB, NOUT, FAM>;
     __shared__ __attribute__((aligned(16))) T lds[(size_t)K::PPB * K::FB::LDS_WORDS_1];
     __shared__ __attribute__((aligned(16))) TwPair<T> imgf[K::FB::IMG_ENTRIES];
     __shared__ __attribute__((aligned(16))) TwPair<T> imgi[K::IB::IMG_ENTRIES];
