@@ -957,6 +957,16 @@ struct ExtWp {
         constexpr uint32_t CM0 = FULL & ~RM0, CMM = FULL & ~RMM, CML = FULL & ~RML, CMIO = FULL & ~IO_RM;
         const uint32_t ebase0 = pdep<CM0>(tid), ebaseM = pdep<CMM>(tid), ebaseL = pdep<CML>(tid), ebaseIO = pdep<CMIO>(tid);
         const uint32_t ntiles = (nb + PPB - 1) / PPB;
+        // NEXT: the next term is loaded while the current one is transformed.  With four 64-bit accumulator tiles the
+        // register file has no room for it (hipcc spilled 100 ... 270 registers): those shapes load each term where it is
+        // used and recompute their layout / image offsets per term from an opaque copy of the thread index (hoisted out
+        // of the term loop they stay live next to the accumulators).  Measured with tools/ext_bench.py (J = 6, N = 512 ...
+        // 2048): four outputs -22 ... -45 % in every class; three outputs -18 ... -23 % for p = 2^64 - c, -10 ... -13 % for
+        // the 62- / 63-bit classes at N = 2048, but +9 ... +19 % for them below and +4 ... +7 % for the double-precision
+        // classes, which keep the prefetch there.
+        constexpr bool NEXT = !(sizeof(T) == 8 &&
+                                (NOUT == 4 || (NOUT == 3 && (CLS == CLS_PM64 || CLS == CLS_GENERIC ||
+                                                             (LOGN >= 11 && (CLS == CLS_LAZY || CLS == CLS_STRICT))))));
         for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
             const uint32_t b = tile * PPB + pl;
             const uint32_t bc = b < nb ? b : nb - 1;  // clamped index for the reads of a ragged tail
@@ -967,27 +977,32 @@ struct ExtWp {
                 for (int e = 0; e < E; ++e) acc[o.value][e] = 0;
             });
             T r[E];
-            FB::template gather<IO_RM>(r, tb, ebaseIO, false);
+            if constexpr (NEXT) FB::template gather<IO_RM>(r, tb, ebaseIO, false);
             for (uint32_t j = 0; j < nterms; ++j) {
                 const uint32_t jn = j + 1 < nterms ? j + 1 : j;  // last iteration: harmless re-read
-                T nx[E];
-                FB::template gather<IO_RM>(nx, tb + ((size_t)jn << LOGN), ebaseIO, false);
+                T nx[NEXT ? E : 1];
+                uint32_t tj = tid;
+                if constexpr (!NEXT) asm volatile("" : "+v"(tj));
+                const uint32_t ebIO = NEXT ? ebaseIO : pdep<CMIO>(tj), eb0 = NEXT ? ebase0 : pdep<CM0>(tj);
+                if constexpr (NEXT) FB::template gather<IO_RM>(nx, tb + ((size_t)jn << LOGN), ebaseIO, false);
+                else FB::template gather<IO_RM>(r, tb + ((size_t)j << LOGN), ebIO, false);
 #pragma unroll
                 for (int e = 0; e < E; ++e) r[e] = Bfly<T, CLS>::load_fix(r[e], P);
                 if constexpr (RM0 != IO_RM) {
-                    FB::template scatter<IO_RM>(r, lds, ebaseIO, true);
+                    FB::template scatter<IO_RM>(r, lds, ebIO, true);
                     F::wsync();
-                    FB::template gather<RM0>(r, (const T *)lds, ebase0, true);
+                    FB::template gather<RM0>(r, (const T *)lds, eb0, true);
                     F::wsync();
                 }
                 // NTT-domain values in layout RMM: canonical, or (CLS_FP) range-reduced doubles
-                F::template pass<0, false, true, !Bfly<T, CLS>::FUSED_LAZY>(r, lds, tid, twf, imgf, P);
+                F::template pass<0, false, true, !Bfly<T, CLS>::FUSED_LAZY>(r, lds, tj, twf, imgf, P);
                 if constexpr (Bfly<T, CLS>::IS_FP) {
 #pragma unroll
                     for (int e = 0; e < E; ++e) r[e] = Bfly<T, CLS>::reduce(r[e], P);
                 }
+                const uint32_t ebM = NEXT ? ebaseM : pdep<CMM>(tj);
                 static_for<0, NOUT>([&](auto o) {
-                    mul_acc_key(acc[o.value], r, key_ntt + (((size_t)j * NOUT + o.value) << LOGN), ebaseM, P);
+                    mul_acc_key(acc[o.value], r, key_ntt + (((size_t)j * NOUT + o.value) << LOGN), ebM, P);
                     if constexpr (Bfly<T, CLS>::IS_FP) {  // every product adds at most 0.875 p to the lazy accumulator
                         if ((j + 1u) % (uint32_t)Bfly<T, CLS>::ACC_REDUCE_EVERY == 0u) {
 #pragma unroll
@@ -996,28 +1011,33 @@ struct ExtWp {
                     }
                 });
                 F::wsync();  // the forward transform's last exchange has been read before LDS is reused
+                if constexpr (NEXT) {
 #pragma unroll
-                for (int e = 0; e < E; ++e) r[e] = nx[e];
+                    for (int e = 0; e < E; ++e) r[e] = nx[e];
+                }
             }
             static_for<0, NOUT>([&](auto o) {
                 T(&a)[E] = acc[o.value];
+                uint32_t to = tid;
+                if constexpr (!NEXT) asm volatile("" : "+v"(to));
+                const uint32_t ebIO = NEXT ? ebaseIO : pdep<CMIO>(to), ebL = NEXT ? ebaseL : pdep<CML>(to);
 #pragma unroll
                 for (int e = 0; e < E; ++e) a[e] = Bfly<T, CLS>::pre_inverse(a[e], P);  // lazy accumulator -> inverse input
-                I::template pass<0>(a, lds, tid, twi, imgi, P);  // canonical coefficients, layout RML
+                I::template pass<0>(a, lds, to, twi, imgi, P);  // canonical coefficients, layout RML
                 if constexpr (RML != IO_RM) {
                     F::wsync();
-                    FB::template scatter<RML>(a, lds, ebaseL, true);
+                    FB::template scatter<RML>(a, lds, ebL, true);
                     F::wsync();
-                    FB::template gather<IO_RM>(a, (const T *)lds, ebaseIO, true);
+                    FB::template gather<IO_RM>(a, (const T *)lds, ebIO, true);
                 }
                 T *dst = out + (((size_t)bc * NOUT + o.value) << LOGN);
                 if (accumulate) {
                     T old[E];
-                    FB::template gather<IO_RM>(old, (const T *)dst, ebaseIO, false);
+                    FB::template gather<IO_RM>(old, (const T *)dst, ebIO, false);
 #pragma unroll
                     for (int e = 0; e < E; ++e) a[e] = add_mod<T>(old[e], a[e], P.p);
                 }
-                if (b < nb) FB::template scatter<IO_RM>(a, dst, ebaseIO, false);
+                if (b < nb) FB::template scatter<IO_RM>(a, dst, ebIO, false);
                 F::wsync();
             });
         }

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Fused mul_accumulate chain (external_product_batch) for 32-bit words, N = 1024 ... 4096, every modulus class, 1 ... 4 outputs:
-ms per call and ns per batch element.  One JSON line per shape.
-    python tools/ext32_bench.py [--tag T] [--sizes 2048,4096]"""
+"""Fused mul_accumulate chain (external_product_batch), every modulus class, 1 ... 4 outputs: ms per call and ns per batch
+element.  One JSON line per shape.
+    python tools/ext_bench.py [--bits 32|64] [--tag T] [--sizes 2048,4096] [--outs 1,2,3,4]"""
 import argparse
 import json
 import os
@@ -13,9 +13,11 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 import concrete_ntt_amd as cntt  # noqa: E402
-from concrete_ntt_amd import prime32  # noqa: E402
+from concrete_ntt_amd import prime32, prime64  # noqa: E402
 
-PRIMES = {"lazy30": 1073479681, "strict31": 2147352577, "fpw32": 4293918721}
+PRIMES = {32: {"lazy30": 1073479681, "strict31": 2147352577, "fpw32": 4293918721},
+          64: {"lazy62": 4611686018427322369, "fp50": 1125899904679937, "strict63": 9223372036853661697,
+               "solinas": 18446744069414584321}}
 
 
 def timed(fn, reps=10, ramp_s=0.5):
@@ -38,17 +40,20 @@ def main():
     ap.add_argument("--tag", default="")
     ap.add_argument("--sizes", default="2048,4096")
     ap.add_argument("--terms", type=int, default=6)
+    ap.add_argument("--bits", type=int, default=32)
+    ap.add_argument("--outs", default="1,2,3,4")
     args = ap.parse_args()
     J = args.terms
-    for name, p in PRIMES.items():
+    mod, dt = (prime32, torch.int32) if args.bits == 32 else (prime64, torch.int64)
+    for name, p in PRIMES[args.bits].items():
         for n in [int(x) for x in args.sizes.split(",")]:
-            plan = prime32.Plan.try_new(n, p)
-            nb = (8 << 20) // n     # 8 Mi coefficients per term plane
-            terms = torch.empty(nb * J * n, dtype=torch.int32, device="cuda")
+            plan = mod.Plan.try_new(n, p)
+            nb = ((8 << 20) // n) * 32 // args.bits     # 32 MiB per term plane
+            terms = torch.empty(nb * J * n, dtype=dt, device="cuda")
             cntt.fill_uniform(terms, p, 3)
-            for O in (1, 2, 3, 4):
-                key = torch.empty(J * O * n, dtype=torch.int32, device="cuda")
-                out = torch.zeros(nb * O * n, dtype=torch.int32, device="cuda")
+            for O in [int(x) for x in args.outs.split(",")]:
+                key = torch.empty(J * O * n, dtype=dt, device="cuda")
+                out = torch.zeros(nb * O * n, dtype=dt, device="cuda")
                 cntt.fill_uniform(key, p, 4)
                 ms = timed(lambda: plan.external_product_batch(out, terms, key, J, O, False))
                 print(json.dumps({"tag": args.tag, "prime": name, "n": n, "J": J, "O": O, "batch": nb, "ms": round(ms, 4),
