@@ -464,13 +464,9 @@ def run_rank(args):
     achieved = moved / (fused_ms * 1e-3) / 1e9
     per_transform = 2 * alg_bytes / (fused_ms * 1e-3) / 1e9
 
-    extras = []
-    try:
-        extras = extra_configs(args, torch, cntt, timer, rank, world, dist, dev)
-    except Exception as e:
-        extras = [{"config": "extras", "error": repr(e)}]
-
-    if rank == 0:
+    def write_line(extras, with_cpu_baseline):
+        if rank != 0:
+            return
         units = world * 2 * batch * args.steps        # forward + inverse transforms, all ranks
         out = {
             "metric": METRIC,
@@ -509,7 +505,7 @@ def run_rank(args):
                          "pointwise_frac": 3 * N * 8 * batch / (mul_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "configs": extras,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and with_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(N, P62)
             except Exception as e:  # the baseline is a reported extra, never a reason to lose the bench line
@@ -517,6 +513,34 @@ def run_rank(args):
                                        "sample": "failed: %r" % (e,)}
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
+
+    # The extras (other BASELINE configs; with several ranks also a 16 GiB-per-rank scatter / gather through RCCL) run AFTER
+    # the timed region and must never cost the headline line: a watchdog prints the line without them and ends the rank
+    # if they have not finished in time (a collective that never returns cannot be interrupted from Python).
+    import threading
+    emitted = threading.Lock()
+
+    def emit(extras, with_cpu_baseline=True):
+        if not emitted.acquire(blocking=False):
+            return
+        write_line(extras, with_cpu_baseline)
+
+    def on_timeout():
+        sys.stderr.write("bench.py rank %d: extras still running after %d s -- watchdog\n" % (rank, args.extras_timeout))
+        emit([{"config": "extras", "error": "not finished after %d s (watchdog); the headline numbers above were complete"
+                                            % args.extras_timeout}], with_cpu_baseline=False)
+        os._exit(0)
+
+    watchdog = threading.Timer(args.extras_timeout, on_timeout)
+    watchdog.daemon = True
+    watchdog.start()
+    extras = []
+    try:
+        extras = extra_configs(args, torch, cntt, timer, rank, world, dist, dev)
+    except Exception as e:
+        extras = [{"config": "extras", "error": repr(e)}]
+    watchdog.cancel()
+    emit(extras)
     os.close(json_fd)
     if dist is not None:
         dist.barrier()
@@ -545,6 +569,9 @@ def main():
     ap.add_argument("--dry-run", action="store_true",
                     help="launch / rendezvous plumbing only (gloo, no GPU, no transform); prints a line with value null")
     ap.add_argument("--launch-timeout", type=int, default=1500, help="seconds the launcher waits for its ranks")
+    ap.add_argument("--extras-timeout", type=int, default=420,
+                    help="seconds the extras (C3 / C4 / C5 legs after the timed region) may take before a watchdog prints the "
+                         "line without them")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
