@@ -65,6 +65,22 @@ CASES = [
     (64, 8192, 1125899904679937, 2, 4, 1),
     (64, 8192, 18446744073707716609, 2, 1, 2),  # 2^64 - c
     (64, 16384, P62, 2, 1, 1),                  # beyond: composed path
+    # three / four 64-bit accumulator tiles: the shapes that run without the next-term prefetch (ExtWp NEXT = false) ...
+    (64, 2048, P62, 3, 3, 3),
+    (64, 2048, P63, 2, 4, 2),
+    (64, 512, SOLINAS, 3, 3, 5),                # 2^64 - c, three outputs
+    (64, 1024, 18446744073707716609, 2, 4, 3),  # 2^64 - c, four outputs
+    (64, 1024, 1125899904679937, 13, 4, 2),     # CLS_FP, four outputs, more terms than the accumulator's reduction period
+    (64, 2048, 2251799813554177, 3, 4, 2),      # CLS_FP51
+    (64, 1024, 9224497936763846657, 3, 4, 2),   # Montgomery class (p >= 2^63, not 2^64 - c)
+    (64, 256, 9224497936763846657, 2, 3, 5),
+    # ... and 32-bit words on the 16-coefficient schedules (four outputs; p >= 2^31 from two / three outputs on)
+    (32, 2048, P30, 3, 4, 3),
+    (32, 4096, P31, 2, 4, 2),
+    (32, 2048, P32, 2, 2, 3),
+    (32, 2048, P32, 5, 3, 2),
+    (32, 4096, P32, 2, 3, 2),
+    (32, 4096, P32, 2, 4, 1),
 ]
 
 
