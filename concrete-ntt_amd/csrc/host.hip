@@ -1274,6 +1274,13 @@ static int product_split_device(const cntt_product *pl, ProductView v, const uin
 static hipError_t product_fused2_try(const cntt_product *pl, bool inv, uint64_t *standard, uint32_t *res32, size_t batch,
                                      bool flag, hipStream_t st, int *rc_out) {
     if (pl->p32.size() != 2 || !pl->p64.empty() || batch == 0 || batch >= ((size_t)1 << 32)) return hipErrorNotSupported;
+    // Round 3: with the element-wise kernels on uncapped grids the composed forward (split kernel + two batched transforms) is
+    // 8 % faster than the fused forward kernel (N = 2048, 32768 polynomials: 0.497 vs 0.542 ms) -- the fused one reads its
+    // twiddles from L2 at three wavefronts per SIMD, the batched transforms from an LDS image -- while the fused inverse
+    // (two transforms + Garner, no residue round trip) still wins (Replace 0.445 vs 0.522 ms; Accumulate 0.599 vs 0.582: a
+    // tie).  CNTT_PRODUCT_FUSED = 0 / 1 forces neither / both for A/B timing; results are identical (tests/test_product.py).
+    static const int force = [] { const char *e = std::getenv("CNTT_PRODUCT_FUSED"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+    if (force == 0 || (force < 0 && !inv)) return hipErrorNotSupported;
     const cntt_plan32 *q0 = pl->p32[0].get(), *q1 = pl->p32[1].get();
     const int cls = transform_class(q0);  // both primes above 2^31 (the reference's fast-path shape): CLS_FPW
     if (cls != transform_class(q1)) return hipErrorNotSupported;
