@@ -259,25 +259,47 @@ __device__ __forceinline__ void native_product(typename NativeShape<KIND>::W *__
             for (int j = 0; j < E; ++j) park[((size_t)i * E + j) * BLK + threadIdx.x] = a[j];
         }
     };
+    // (n = 32768, 32 coefficients per thread: past hipcc's inlining budget the per-prime lambdas stay calls and everything they
+    // capture -- kernel arguments, the register tiles -- moves to scratch memory; the call sites force them in.  Not for the
+    // smaller sizes: forced there the LDS-parked kernels want 237 instead of 108 VGPRs.)
+    constexpr bool FORCE_INLINE = E > 16;
     if constexpr ((OPT & NF_ROLL) != 0) {
         // one copy of the three transforms for the parked primes (a runtime loop: tables and constants of prime i come
         // from the kernel arguments by scalar loads) and one for the last: a fifth (a tenth for native128) of the code
 #pragma clang loop unroll(disable)
         for (int i = 0; i < KP - 1; ++i) {
             uint32_t a[E];
-            one_prime(i, a);
-            park_tile(i, a);
+            if constexpr (FORCE_INLINE) {
+                [[clang::always_inline]] one_prime(i, a);
+                [[clang::always_inline]] park_tile(i, a);
+            } else {
+                one_prime(i, a);
+                park_tile(i, a);
+            }
         }
-        one_prime(KP - 1, last);
+        if constexpr (FORCE_INLINE) {
+            [[clang::always_inline]] one_prime(KP - 1, last);
+        } else {
+            one_prime(KP - 1, last);
+        }
     } else {
         static_for<0, KP>([&](auto ic) {
             constexpr int i = ic.value;
             if constexpr (i == KP - 1) {
-                one_prime(i, last);
+                if constexpr (FORCE_INLINE) {
+                    [[clang::always_inline]] one_prime(i, last);
+                } else {
+                    one_prime(i, last);
+                }
             } else {
                 uint32_t a[E];
-                one_prime(i, a);
-                park_tile(i, a);
+                if constexpr (FORCE_INLINE) {
+                    [[clang::always_inline]] one_prime(i, a);
+                    [[clang::always_inline]] park_tile(i, a);
+                } else {
+                    one_prime(i, a);
+                    park_tile(i, a);
+                }
             }
         });
     }

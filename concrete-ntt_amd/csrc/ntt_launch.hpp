@@ -72,8 +72,8 @@ struct ProductArgs;
 // ProductFusedTables.  hipErrorNotSupported for other sizes.
 hipError_t launch_product_fused2(int logn, int cls, bool inv, uint64_t *standard, uint32_t *res32, const void *tables,
                                  const ProductArgs &A, uint32_t batch, bool flag, hipStream_t st);
-// The persistent form of the kernel (n = 16384 of every kind, n = 8192 of the kinds that do not fit LDS there, native128 = kind 2
-// at every size) parks residue
+// The persistent form of the kernel (n = 16384 / 32768 of every kind, n = 8192 of the kinds that do not fit LDS there, native128 =
+// kind 2 at every size) parks residue
 // tiles in `scratch` (native_fused_scratch_words() 32-bit words); the other shapes ignore it.
 template <int KIND>
 hipError_t launch_native_fused(int logn, void *prod, const void *lhs, const void *rhs, const void *tables, const SplitArgs &S,
@@ -86,15 +86,15 @@ inline int device_num_cus() {
 }
 constexpr bool native_fused_lds13(int kind) { return kind == 0 || kind == 1 || kind == 4; }  // n = 8192 with the tiles in LDS (native_fused_inst.inc)
 inline bool native_fused_persistent(int kind, int logn) {
-    return (logn == 13 && !native_fused_lds13(kind)) || logn == 14 || (kind == 2 && logn >= 5 && logn <= 12);
+    return (logn == 13 && !native_fused_lds13(kind)) || logn == 14 || logn == 15 || (kind == 2 && logn >= 5 && logn <= 12);
 }
 // words of one residue tile of a workgroup (256 threads x 16 coefficients hold 4096 / n products below n = 4096)
 inline size_t native_fused_tile_words(int logn) { return logn < 12 ? (size_t)4096 : (size_t)1 << logn; }
 // workgroups of the persistent kernel: what is resident on `ncu` compute units (four 256-thread workgroups per unit for
-// native128 below n = 8192, two 512-thread ones at n = 8192, one 1024-thread one at n = 16384), at most one per group of products
+// native128 below n = 8192, two 512-thread ones at n = 8192, one 1024-thread one at n = 16384 / 32768), at most one per group of products
 inline uint32_t native_fused_grid(int logn, int ncu, uint32_t batch) {
     const size_t ppb = native_fused_tile_words(logn) >> logn;
-    const size_t groups = ((size_t)batch + ppb - 1) / ppb, g = (size_t)ncu * (logn == 14 ? 1u : logn == 13 ? 2u : 4u);
+    const size_t groups = ((size_t)batch + ppb - 1) / ppb, g = (size_t)ncu * (logn >= 14 ? 1u : logn == 13 ? 2u : 4u);
     return (uint32_t)(g < groups ? g : groups);
 }
 inline size_t native_fused_scratch_words(int kind, int logn, int nprimes, int ncu, uint32_t batch) {

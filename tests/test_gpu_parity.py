@@ -549,12 +549,12 @@ def test_native128_polymul_persistent_kernel(oracle, n):
     assert torch.equal(dp, _composed_polymul(torch, plan, cls, dl, dr, batch, n)), n
 
 
-@pytest.mark.parametrize("n", [8192, 16384])
+@pytest.mark.parametrize("n", [8192, 16384, 32768])
 @pytest.mark.parametrize("kind", ["native32_plan32", "native64_plan32", "native128_plan32", "native_binary32_plan32",
                                   "native_binary64_plan32", "native_binary128_plan32"])
 def test_native_polymul_large_n(oracle, kind, n):
-    """N = 8192 / 16384 run the persistent whole-product kernel whose workgroups park residue tiles in the plan's
-    workspace (csrc/native_fused.hpp, native_polymul_kernel_g).  A batch larger than the grid (every workgroup loops, the
+    """N = 8192 (some kinds) / 16384 / 32768 run the persistent whole-product kernel whose workgroups park residue tiles
+    in the plan's workspace (csrc/native_fused.hpp, native_polymul_kernel_g; 32 coefficients per thread at 32768).  A batch larger than the grid (every workgroup loops, the
     last round is ragged): the first, the last and a few middle products against the oracle, and every product against the
     composed split -> transforms -> pointwise -> CRT pipeline."""
     torch = _torch()
