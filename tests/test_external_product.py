@@ -53,7 +53,7 @@ CASES = [
     (32, 4096, P31, 2, 2, 3),        # fused u32, 32 registers per thread
     (32, 64, P32, 3, 3, 7),          # fused u32, generic class
     (32, 8192, P30, 2, 1, 2),        # composed u32
-    # the chain on the wave-block walk (ExtBlk): u64 n = 4096 / 8192, every class but the Montgomery one, 1 .. 4 outputs
+    # the chain on the wave-block walk (ExtBlk): u64 n = 4096 / 8192 (1 .. 4 outputs) and 16384 (1 .. 2), every class but the Montgomery one
     (64, 4096, P62, 3, 2, 3),
     (64, 4096, P62, 2, 1, 2),
     (64, 4096, P62, 2, 3, 2),
@@ -64,7 +64,12 @@ CASES = [
     (64, 8192, P62, 2, 2, 2),
     (64, 8192, 1125899904679937, 2, 4, 1),
     (64, 8192, 18446744073707716609, 2, 1, 2),  # 2^64 - c
-    (64, 16384, P62, 2, 1, 1),                  # beyond: composed path
+    (64, 16384, P62, 2, 1, 1),                  # n = 16384: the wave-block chain for one / two outputs (128 VGPRs) ...
+    (64, 16384, P62, 3, 2, 2),
+    (64, 16384, 1125899904679937, 9, 2, 2),     # CLS_FP: more terms than the accumulator's reduction period
+    (64, 16384, SOLINAS, 2, 2, 1),
+    (64, 16384, P63, 2, 1, 2),
+    (64, 16384, P62, 2, 3, 1),                  # ... three outputs: composed path
     # three / four 64-bit accumulator tiles: the shapes that run without the next-term prefetch (ExtWp NEXT = false) ...
     (64, 2048, P62, 3, 3, 3),
     (64, 2048, P63, 2, 4, 2),
