@@ -892,6 +892,58 @@ __global__ __launch_bounds__(WPB, WPW) void mul_kernel_wp(T *__restrict__ lhs, c
     K::run(lhs, rhs_ntt, twf, twi, P, nsub, lds, imgf, imgi);
 }
 
+// The same fused product for the sizes that have no LDS twiddle image (32-bit words, N = 8192 ... 32768): one polynomial per
+// workgroup, twiddles from the tables in global memory (L2), no persistent walk -- several workgroups per CU in different
+// phases overlap loads, butterflies and stores, as for the stand-alone transforms of these sizes.  3 N words of HBM traffic
+// instead of 7 N and one launch instead of three.
+template <class T, int LOGN, int CLS>
+struct MulOne {
+    static constexpr int TPP = NttKernel<T, LOGN, false, CLS, false>::TPP;
+    using F = NttWp<T, LOGN, false, CLS, TPP>;
+    using I = NttWp<T, LOGN, true, CLS, TPP>;
+    using FB = typename F::B;
+    using IB = typename I::B;
+    static constexpr int E = FB::E, NPASS = FB::NPASS;
+    static constexpr uint32_t FULL = FB::FULL;
+    static constexpr uint32_t RM0 = FB::S::RMASK[0], RMM = FB::S::RMASK[NPASS - 1], RML = IB::S::RMASK[NPASS - 1];
+    static_assert(RMM == IB::S::RMASK[0], "forward and inverse schedules must mirror each other");
+
+    static __device__ __forceinline__ void run(T *__restrict__ lhs, const T *__restrict__ rhs_ntt,
+                                               const TwPair<T> *__restrict__ twf, const TwPair<T> *__restrict__ twi,
+                                               const ModParams<T> &P, T *lds) {
+        constexpr uint32_t CM0 = FULL & ~RM0, CMM = FULL & ~RMM, CML = FULL & ~RML;
+        const uint32_t tid = threadIdx.x;
+        T *base = lhs + ((size_t)blockIdx.x << LOGN);
+        T r[E];
+        FB::template gather<RM0>(r, (const T *)base, pdep<CM0>(tid), false);
+#pragma unroll
+        for (int j = 0; j < E; ++j) r[j] = Bfly<T, CLS>::load_fix(r[j], P);
+        // NTT-domain values in layout RMM: canonical, or the lazy form mul_for_inv takes
+        F::template pass<0, false, false, !Bfly<T, CLS>::FUSED_LAZY>(r, lds, tid, twf, nullptr, P);
+        {
+            T b[E];
+            FB::template gather_tile<RMM>(b, rhs_ntt + ((size_t)blockIdx.x << LOGN), pdep<CMM>(tid) * (uint32_t)sizeof(T));
+#pragma unroll
+            for (int j = 0; j < E; ++j) r[j] = mul_for_inv<T, CLS>(r[j], b[j], P);  // 1/N: inside the last inverse stage
+        }
+        F::wsync();  // the forward transform's last exchange has been read before the inverse overwrites it
+        uint32_t ti = tid;   // fresh opaque copy: no address of the forward half stays live into the inverse half
+        asm volatile("" : "+v"(ti));
+        I::template pass<0, true, false>(r, lds, ti, twi, nullptr, P);  // canonical coefficients, layout RML
+        FB::template scatter<RML>(r, base, pdep<CML>(ti), false);
+    }
+};
+
+template <class T, int LOGN, int CLS>
+__global__ __launch_bounds__((MulOne<T, LOGN, CLS>::TPP)) void mul_kernel_one(T *__restrict__ lhs, const T *__restrict__ rhs_ntt,
+                                                                           const TwPair<T> *__restrict__ twf,
+                                                                           const TwPair<T> *__restrict__ twi,
+                                                                           const ModParams<T> P) {
+    using K = MulOne<T, LOGN, CLS>;
+    __shared__ __attribute__((aligned(16))) T lds[K::FB::LDS_WORDS_1];
+    K::run(lhs, rhs_ntt, twf, twi, P, lds);
+}
+
 // -------------------------------------------------------------------------------------------------
 // Fused mul_accumulate chain (the step around the NTT in the reference's caller):
 //     for each o < NOUT:  out[b][o] (+)= inv( sum_{j < J} fwd(terms[b][j]) (.) key_ntt[j][o] )

@@ -104,7 +104,7 @@ int cntt_prime64_mul_accumulate_batch(const cntt_plan64_t *plan, uint64_t *acc, 
 /* Fused lhs <- inv(mul_assign_normalize(fwd(lhs), rhs_ntt)): the composition a caller of the reference writes as
  * plan.fwd(a); plan.mul_assign_normalize(a, b_ntt); plan.inv(a)  (examples/mul_poly_prime.rs, src/prime64.rs:1254-1266),
  * i.e. the negacyclic product of lhs with the polynomial whose forward transform is rhs_ntt, in one pass over HBM
- * for n <= 32768 (u64; n >= 4096 except the Montgomery-class moduli) / 4096 (u32), three launches otherwise.  Same
+ * for n <= 32768 (u64: n >= 4096 except the Montgomery-class moduli), three launches otherwise.  Same
  * values as the three separate calls. */
 int cntt_prime64_mul_ntt_batch(const cntt_plan64_t *plan, uint64_t *lhs, const uint64_t *rhs_ntt, size_t batch, cntt_mem_t where, void *stream);
 /* Fused mul_accumulate chain, the composition a caller of the reference writes around the NTT as

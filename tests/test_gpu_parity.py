@@ -238,10 +238,15 @@ def test_test_product_property(oracle, plans):
                                       (64, 1024, 9223372036853661697), (64, 512, 18446744069414584321),
                                       (64, 1024, 18446744073707716609), (64, 16, P62),
                                       (32, 64, 1062862849), (32, 1024, 1062862849), (32, 1024, 2147352577),
-                                      (32, 512, 4293918721), (32, 4096, 1062862849), (32, 32, 1073479681)])
+                                      (32, 512, 4293918721), (32, 4096, 1062862849), (32, 32, 1073479681),
+                                      # 32-bit words above n = 4096: one polynomial per workgroup (mul_kernel_one), every class
+                                      (32, 8192, 1062862849), (32, 8192, 2147352577), (32, 8192, 4293918721),
+                                      (32, 16384, 1062862849), (32, 16384, 4293918721), (32, 16384, 2147352577),
+                                      (32, 32768, 1062862849), (32, 32768, 2147352577), (32, 32768, 4293918721),
+                                      (32, 65536, 1062862849)])
 def test_fused_mul_ntt_equals_three_calls(oracle, plans, oplans, bits, n, p):
     """cntt_prime*_mul_ntt_batch == fwd; mul_assign_normalize; inv (src/prime64.rs:1254-1266), ragged batches,
-    fused kernel (n <= 1024) and the three-launch fallback."""
+    the fused kernels and the three-launch fallback (n = 65536)."""
     plan, ref = plans(bits, n, p), oplans(bits, n, p)
     for batch in (1, 13, 301):
         a = oracle.fill_uniform(batch * n, p, 31 + batch, bits)
