@@ -1097,6 +1097,86 @@ struct ExtWp {
     }
 };
 
+// The chain for the sizes without an LDS twiddle image (32-bit words, N = 8192 ... 32768): one batch element per workgroup,
+// twiddles from the tables in global memory (L2), no persistent walk and no next-term prefetch (several workgroups per CU in
+// different phases overlap loads and butterflies, as MulOne).  Same values as ExtWp.
+template <class T, int LOGN, int CLS, int NOUT>
+struct ExtOne {
+    static constexpr int TPP = NttKernel<T, LOGN, false, CLS, false>::TPP;
+    using X = ExtWp<T, LOGN, CLS, TPP, NOUT>;
+    using F = typename X::F;
+    using I = typename X::I;
+    using FB = typename X::FB;
+    static constexpr int E = X::E;
+    static constexpr uint32_t FULL = X::FULL, RM0 = X::RM0, RMM = X::RMM, RML = X::RML;
+
+    static __device__ __forceinline__ void run(T *__restrict__ out, const T *__restrict__ terms, const T *__restrict__ key_ntt,
+                                               const TwPair<T> *__restrict__ twf, const TwPair<T> *__restrict__ twi,
+                                               const ModParams<T> &P, uint32_t nterms, bool accumulate, T *lds) {
+        constexpr uint32_t CM0 = FULL & ~RM0, CMM = FULL & ~RMM, CML = FULL & ~RML;
+        const uint32_t tid = threadIdx.x, b = blockIdx.x;
+        const T *tb = terms + (((size_t)b * nterms) << LOGN);
+        T acc[NOUT][E];
+        static_for<0, NOUT>([&](auto o) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) acc[o.value][e] = 0;
+        });
+        for (uint32_t j = 0; j < nterms; ++j) {
+            uint32_t tj = tid;   // per-term opaque copy: no offset of the transform stays live next to the accumulators
+            asm volatile("" : "+v"(tj));
+            T r[E];
+            FB::template gather<RM0>(r, tb + ((size_t)j << LOGN), pdep<CM0>(tj), false);
+#pragma unroll
+            for (int e = 0; e < E; ++e) r[e] = Bfly<T, CLS>::load_fix(r[e], P);
+            F::template pass<0, false, false, !Bfly<T, CLS>::FUSED_LAZY>(r, lds, tj, twf, nullptr, P);
+            if constexpr (Bfly<T, CLS>::IS_FP) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) r[e] = Bfly<T, CLS>::reduce(r[e], P);
+            }
+            const uint32_t ebM = pdep<CMM>(tj);
+            static_for<0, NOUT>([&](auto o) {
+                X::mul_acc_key(acc[o.value], r, key_ntt + (((size_t)j * NOUT + o.value) << LOGN), ebM, P);
+                if constexpr (Bfly<T, CLS>::IS_FP) {
+                    if ((j + 1u) % (uint32_t)Bfly<T, CLS>::ACC_REDUCE_EVERY == 0u) {
+#pragma unroll
+                        for (int e = 0; e < E; ++e) acc[o.value][e] = Bfly<T, CLS>::reduce(acc[o.value][e], P);
+                    }
+                }
+            });
+            F::wsync();  // the forward transform's last exchange has been read before LDS is reused
+        }
+        static_for<0, NOUT>([&](auto o) {
+            T(&a)[E] = acc[o.value];
+            uint32_t to = tid;
+            asm volatile("" : "+v"(to));
+#pragma unroll
+            for (int e = 0; e < E; ++e) a[e] = Bfly<T, CLS>::pre_inverse(a[e], P);
+            I::template pass<0, false, false>(a, lds, to, twi, nullptr, P);  // canonical coefficients, layout RML
+            T *dst = out + (((size_t)b * NOUT + o.value) << LOGN);
+            if (accumulate) {
+                T old[E];
+                FB::template gather<RML>(old, (const T *)dst, pdep<CML>(to), false);
+#pragma unroll
+                for (int e = 0; e < E; ++e) a[e] = add_mod<T>(old[e], a[e], P.p);
+            }
+            FB::template scatter<RML>(a, dst, pdep<CML>(to), false);
+            F::wsync();
+        });
+    }
+};
+
+template <class T, int LOGN, int CLS, int NOUT>
+__global__ __launch_bounds__((ExtOne<T, LOGN, CLS, NOUT>::TPP)) void ext_kernel_one(T *__restrict__ out, const T *__restrict__ terms,
+                                                                                 const T *__restrict__ key_ntt,
+                                                                                 const TwPair<T> *__restrict__ twf,
+                                                                                 const TwPair<T> *__restrict__ twi,
+                                                                                 const ModParams<T> P, uint32_t nterms,
+                                                                                 uint32_t accumulate) {
+    using K = ExtOne<T, LOGN, CLS, NOUT>;
+    __shared__ __attribute__((aligned(16))) T lds[K::FB::LDS_WORDS_1];
+    K::run(out, terms, key_ntt, twf, twi, P, nterms, accumulate != 0, lds);
+}
+
 template <class T, int LOGN, int CLS, int WPB, int WPW, int NOUT, int FAM = 0>
 __global__ __launch_bounds__(WPB, WPW) void ext_kernel_wp(T *__restrict__ out, const T *__restrict__ terms,
                                                       const T *__restrict__ key_ntt, const TwPair<T> *__restrict__ twf,

@@ -52,7 +52,13 @@ CASES = [
     (32, 1024, P30, 6, 2, 5),        # fused u32
     (32, 4096, P31, 2, 2, 3),        # fused u32, 32 registers per thread
     (32, 64, P32, 3, 3, 7),          # fused u32, generic class
-    (32, 8192, P30, 2, 1, 2),        # composed u32
+    (32, 8192, P30, 2, 1, 2),        # u32 above n = 4096: one batch element per workgroup (ExtOne) ...
+    (32, 8192, P31, 3, 4, 2),
+    (32, 16384, P30, 3, 2, 3),
+    (32, 16384, P32, 2, 3, 2),       # p >= 2^31 on doubles
+    (32, 32768, P30, 2, 2, 2),
+    (32, 32768, P32, 2, 1, 1),       # Montgomery class at this size
+    (32, 32768, P30, 2, 3, 1),       # ... three outputs at n = 32768: composed path
     # the chain on the wave-block walk (ExtBlk): u64 n = 4096 / 8192 (1 .. 4 outputs) and 16384 (1 .. 2), every class but the Montgomery one
     (64, 4096, P62, 3, 2, 3),
     (64, 4096, P62, 2, 1, 2),

@@ -48,7 +48,7 @@ def main():
     for name, p in PRIMES[args.bits].items():
         for n in [int(x) for x in args.sizes.split(",")]:
             plan = mod.Plan.try_new(n, p)
-            nb = ((8 << 20) // n) * 32 // args.bits     # 32 MiB per term plane
+            nb = ((32 << 20) // n) * 32 // args.bits     # 128 MiB per term plane
             terms = torch.empty(nb * J * n, dtype=dt, device="cuda")
             cntt.fill_uniform(terms, p, 3)
             for O in [int(x) for x in args.outs.split(",")]:
