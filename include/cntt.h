@@ -193,8 +193,8 @@ int cntt_native_fwd_binary_batch(const cntt_native_t *plan, const void *value, v
 int cntt_native_inv_batch(const cntt_native_t *plan, void *value, void *const *residues, size_t batch, cntt_mem_t where, void *stream);
 /* The device path of the Plan32 kinds is one kernel for 32 <= n <= 32768.  n <= 4096 (except native128) needs no
  * workspace (nor n = 8192 of native32 / native64 / native_binary64); the other n = 8192 kinds, n = 16384 / 32768 and native128 park
- * residue tiles in a per-plan, per-device workspace of a few tens of MiB
- * (independent of the batch); the Plan52 kinds run the composed pipeline on a workspace of
+ * residue tiles in a per-plan, per-device workspace of a few tens of MiB (n = 32768: 64 ... 300 MiB, native128 the most),
+ * independent of the batch; the Plan52 kinds run the composed pipeline on a workspace of
  * 2 * nprimes * batch * n residues.  The workspace grows on demand (an allocation, and a device synchronisation when it
  * is replaced): reserve it ahead of a timed or captured region with cntt_native_reserve().  Calls on different streams
  * that share a plan are ordered against each other by the library wherever they share the workspace -- EXCEPT while a
