@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Extended run of the seeded random GPU parity sweeps (tests/test_gpu_random.py) over many more seeds than the
 test suite uses: prime plans, native polymul plans, product plans.  Prints the failing seeds, if any.
-    python tools/soak_random.py [extra_seeds_per_family] [plans|native|product]"""
+    python tools/soak_random.py [extra_seeds_per_family] [plans|native|product|chain]
+`chain`: the fused mul_accumulate chain kernels with batches of more than two rounds of their persistent grids (random
+primes of every class, random sizes / terms / outputs; tests/test_external_product_multitrip.py::run_chain_case)."""
 import os
 import sys
 
@@ -31,5 +33,24 @@ for name, fn, first in (("plans", t.test_gpu_random_plans, 24), ("native", t.tes
         if seed % 20 == 0:
             print(name, "seed", seed, flush=True)  # progress (a silent GPU job is taken for hung)
     print(name, "done", flush=True)
+if only in (None, "chain"):
+    import random
+    import test_external_product_multitrip as mt
+    for seed in range(extra if only == "chain" else max(extra // 10, 1)):
+        rng = random.Random(7000 + seed)
+        bits = 64 if seed % 2 == 0 else 32
+        n = 1 << (rng.randint(10, 14) if bits == 64 else rng.randint(10, 12))   # the grid-round sizes of run_chain_case assume n >= 1024
+        p = t._random_prime(oracle, rng, bits, n, top=seed % 3 == 0)
+        J, O = rng.randint(1, 3), rng.randint(1, 2 if n == 16384 else 4)
+        kernel = "blk" if bits == 64 and n >= 4096 else "wp"
+        try:
+            mt.run_chain_case(oracle, bits, n, p, J, O, kernel, bool(seed & 2), 100 + seed)
+        except BaseException as e:
+            if type(e).__name__ == "Skipped":
+                continue
+            bad += 1
+            print("FAIL chain", seed, (bits, n, p, J, O), repr(e)[:300], flush=True)
+        print("chain seed", seed, (bits, n, p, J, O), flush=True)
+    print("chain done", flush=True)
 print("soak done, failures:", bad)
 sys.exit(1 if bad else 0)
