@@ -162,12 +162,31 @@ def make_sched_fam2(bits, logn, inv):
     return Sched(bits, logn, inv, 4, passes, [], tpp, BLK_PAD)
 
 
+# FAM 3 (32-bit words, round 4): the passes of family 1 (16 coefficients per thread wherever the size allows) with a PADDED
+# exchange layout instead of the XOR swizzle -- for the whole-product kernels of the native plans (native_fused.hpp), which
+# are bound by their VALU instruction count: the swizzled address of every 4-byte LDS access costs a shift / xor / or
+# triple (1950 of 15500 instructions per thread in the N = 4096 native64 product), the padded one is one base per pass plus
+# the DS instruction's immediate offset.  Paddings by exhaustive search over (shift, words) with score() (total over both
+# directions, next to the swizzle's): logn 5..8 conflict-free like the swizzle; 9: 10 vs 9; 10: 10 vs 9; 11, 12: 9 vs 9;
+# 13, 14: 14 vs 13; 15: 8 vs 9.  Every padding is a multiple of four words behind a multiple of four: 16-byte accesses stay aligned.
+FAM3_PAD = {5: (4, 4), 6: (4, 4), 7: (4, 4), 8: (4, 4), 9: (7, 8), 10: (6, 4), 11: (6, 4), 12: (6, 4), 13: (7, 8), 14: (6, 4),
+            15: (5, 4)}
+
+
+def fam3_supported(bits, logn):
+    return bits == 32 and logn in FAM3_PAD
+
+
 def make_sched(bits, logn, inv, fam=0):
     """fam 0: the tuned schedule; fam 1: the 16-coefficients-per-thread schedule where fam 0 overrides LOGE
     (the whole-polymul kernels keep K residue tiles in registers and cannot afford 32 per thread);
-    fam 2: wave blocks (make_sched_fam2)."""
+    fam 2: wave blocks (make_sched_fam2); fam 3: family 1 with a padded exchange layout."""
     if fam == 2:
         return make_sched_fam2(bits, logn, inv)
+    if fam == 3:
+        assert fam3_supported(bits, logn)
+        b = make_sched(bits, logn, inv, 1)
+        return Sched(bits, logn, inv, b.loge, b.passes, [], b.block, FAM3_PAD[logn])
     ov = OVERRIDES.get((bits, logn, inv), {})
     if fam == 1:
         ov = {k: v for k, v in ov.items() if k != "loge"}
@@ -329,6 +348,8 @@ def emit(path):
                     keys.append((bits, logn, inv, 1))
                 if fam2_supported(bits, logn):
                     keys.append((bits, logn, inv, 2))
+                if fam3_supported(bits, logn):
+                    keys.append((bits, logn, inv, 3))
     for bits, logn, inv, fam in keys:
             if True:
                 s = make_sched(bits, logn, inv, fam)
@@ -363,10 +384,12 @@ def check():
                 pass
             pl = gg.Plan(n, p, bits)
             a = [rnd.randrange(p) for _ in range(n)]
-            for inv, fam in ((False, 0), (True, 0), (False, 1), (True, 1), (False, 2), (True, 2)):
+            for inv, fam in ((False, 0), (True, 0), (False, 1), (True, 1), (False, 2), (True, 2), (False, 3), (True, 3)):
                 if fam == 1 and "loge" not in OVERRIDES.get((bits, logn, inv), {}):
                     continue
                 if fam == 2 and not fam2_supported(bits, logn):
+                    continue
+                if fam == 3 and not fam3_supported(bits, logn):
                     continue
                 s = make_sched(bits, logn, inv, fam)
                 table = pl.inv_twid if inv else pl.twid

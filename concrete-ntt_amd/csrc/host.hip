@@ -57,10 +57,14 @@ extern "C" int cntt_device_count(void) {
 // Grid of the element-wise kernels (grid-stride loops: any grid is correct): one 256-thread block per 256 work items, NOT capped at
 // a few blocks per CU.  Measured (tools/pw_probe.py, 65536 x 1024 u64): mul_assign_normalize 0.374 -> 0.271 ms (4.3 -> 5.9 TB/s),
 // normalize 0.232 -> 0.178 ms (4.6 -> 6.0 TB/s) against the 2048-block persistent form; split / CRT / Garner kernels -4 ... -7 %.
-static inline unsigned ew_grid(size_t work_items) {
+// The cap: a dispatch holds at most 2^32 - 1 work-items per dimension (grid_size_x of the AQL packet is a uint32), i.e. fewer than
+// 2^24 blocks of 256 threads; beyond it (16 GiB of u32 and up -- plausible on 288 GB) the kernels' 64-bit grid-stride loops
+// take over.
+extern "C" unsigned cntt_ew_grid(size_t work_items) {
     const size_t blocks = (work_items + 255) / 256;
-    return (unsigned)std::max<size_t>(1, std::min<size_t>(blocks, (size_t)1 << 30));
+    return (unsigned)std::max<size_t>(1, std::min<size_t>(blocks, ((size_t)1 << 24) - 1));
 }
+static inline unsigned ew_grid(size_t work_items) { return cntt_ew_grid(work_items); }
 
 // ---------------------------------------------------------------------------------------------
 // prime plans
@@ -714,6 +718,11 @@ struct cntt_native {
     std::vector<std::unique_ptr<cntt_plan32>> p32;
     std::vector<std::unique_ptr<cntt_plan64>> p64;
     CrtArgs crt{};
+    // accumulating CRT of the whole-product kernel (native_fused.hpp, native_product_acc): constants, and the per-prime
+    // parameters whose last-inverse-stage constants carry (M / P_i)^-1 / n
+    AccArgs acc{};
+    ModParams<uint32_t> mp_acc[10];
+    bool has_acc = false;
     std::shared_ptr<NativeCache> cache;
     size_t rbytes() const { return info.is52 ? 8 : 4; }
     uint64_t prime(int i) const { return info.is52 ? PRIMES52[i] : (uint64_t)PRIMES32[i]; }
@@ -767,6 +776,49 @@ static void build_crt_args(cntt_native *pl) {
     A.prefix_hi[I.ngroups] = (uint64_t)(prefix >> 64);
 }
 
+// Plan32 kinds: M = P_0 ... P_{k-1}, M_i = M / P_i, y_i = M_i^-1 mod P_i (Euler, like src/lib.rs:541-551)
+static void build_acc_args(cntt_native *pl) {
+    const int k = pl->info.nprimes;
+    if (pl->info.is52) return;
+    AccArgs &A = pl->acc;
+    std::memset(&A, 0, sizeof A);
+    u128 m = 1;  // mod 2^128
+    for (int i = 0; i < k; ++i) m *= (u128)PRIMES32[i];
+    A.m_lo = (uint64_t)m;
+    A.m_hi = (uint64_t)(m >> 64);
+    for (int i = 0; i < k; ++i) {
+        const uint64_t p = PRIMES32[i];
+        u128 mi = 1;         // M_i mod 2^128
+        uint64_t mi_p = 1;   // M_i mod P_i
+        for (int h = 0; h < k; ++h) {
+            if (h == i) continue;
+            mi *= (u128)PRIMES32[h];
+            mi_p = host::mulmod(mi_p, PRIMES32[h] % p, p);
+        }
+        A.c_lo[i] = (uint64_t)mi;
+        A.c_hi[i] = (uint64_t)(mi >> 64);
+        A.f[i] = (uint32_t)((((uint64_t)1) << (32 + ACC_FRAC_BITS)) / p);
+        A.m60[i] = (uint32_t)((((uint64_t)1) << 60) / p);
+        // the lazy split folds a word 32 bits at a time with t = hi c + lo < 2^58: needs c = 2^32 mod p < 2^26 - 1
+        if (((((uint64_t)1) << 32) % p) >= (((uint64_t)1) << 26) - 1) return;
+        // (M / P_i)^-1 times 2^32: the kernel's pointwise product is a Montgomery product (acc_mont_lazy) and leaves a factor 2^-32
+        const uint64_t y = host::mulmod(host::powmod(mi_p, p - 2, p), (((uint64_t)1) << 32) % p, p);
+        const cntt_plan32 *sub = pl->p32[(size_t)i].get();
+        ModParams<uint32_t> mp = sub->mp;
+        if (mp.cls != CLS_LAZY) return;
+        mp.n_inv = (uint32_t)host::mulmod(mp.n_inv, y, p);
+        mp.n_inv_shoup = shoup_of<uint32_t>(mp.n_inv, (uint32_t)p);
+        mp.last_w = (uint32_t)host::mulmod(mp.last_w, y, p);
+        mp.last_w_shoup = shoup_of<uint32_t>(mp.last_w, (uint32_t)p);
+        pl->mp_acc[i] = mp;
+    }
+    pl->has_acc = true;
+}
+bool cntt::native_acc_enabled() {
+    static const bool on = [] { const char *e = std::getenv("CNTT_NATIVE_ACC"); return !(e && e[0] == '0'); }();  // A/B runs, parity tests
+    return on;
+}
+
 extern "C" int cntt_native_plan_new(cntt_native_kind_t kind, size_t n, cntt_native_t **out) {
     if (!out) return fail(CNTT_EINVAL, "out is NULL");
     *out = nullptr;
@@ -788,6 +840,7 @@ extern "C" int cntt_native_plan_new(cntt_native_kind_t kind, size_t n, cntt_nati
         }
     }
     build_crt_args(pl.get());
+    build_acc_args(pl.get());
     pl->cache = std::make_shared<NativeCache>();
     *out = pl.release();
     return CNTT_OK;
@@ -1022,19 +1075,21 @@ template <int KIND>
 static hipError_t native_fused_try(const cntt_native *pl, void *prod, const void *lhs, const void *rhs, size_t batch,
                                    uint32_t *park, hipStream_t st, int *rc_out) {
     constexpr int KP = NativeShape<KIND>::KP;
-    FusedTables<KP> F{};
+    FusedTables<KP> F{}, Facc{};
     for (int i = 0; i < KP; ++i) {
         DeviceTables<uint32_t> t;
         if (int rc = device_tables(pl->p32[(size_t)i].get(), &t)) {
             *rc_out = rc;
             return hipErrorUnknown;
         }
-        F.twf[i] = t.fwd;
-        F.twi[i] = t.inv;
+        F.twf[i] = Facc.twf[i] = t.fwd;
+        F.twi[i] = Facc.twi[i] = t.inv;
         F.P[i] = pl->p32[(size_t)i]->mp;
+        Facc.P[i] = pl->mp_acc[i];
     }
     const SplitArgs S = native_split_args(pl, nullptr);
-    return launch_native_fused<KIND>(pl->p32[0]->logn, prod, lhs, rhs, &F, S, pl->crt, (uint32_t)batch, park, st);
+    return launch_native_fused<KIND>(pl->p32[0]->logn, prod, lhs, rhs, &F, S, pl->crt, (uint32_t)batch, park, st,
+                                     pl->has_acc ? &pl->acc : nullptr, pl->has_acc ? &Facc : nullptr);
 }
 // CNTT_OK: enqueued; FUSED_NONE: no whole-product kernel for this plan / size (the caller composes)
 static constexpr int FUSED_NONE = -1;

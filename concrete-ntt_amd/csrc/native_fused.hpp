@@ -335,6 +335,242 @@ __device__ __forceinline__ void native_product(typename NativeShape<KIND>::W *__
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same product with an ACCUMULATING CRT (round 4): no residue tile is parked anywhere.
+//
+// negacyclic_polymul's result is the wrapping image of the EXACT integer product c (|c| < n 2^(2 bits(W)), or n 2^bits(W)
+// for the binary plans), and the plans' moduli M = P_0 ... P_{k-1} exceed 2 |c| by at least 2^5.9 (native64 at n = 32768:
+// 2^143 against 2^149.9; every other kind / size has more room).  Any exact reconstruction of c therefore yields the
+// reference's bits (src/native64.rs:91-141: its digits v0, v12, v34 and the sign test on the top digit describe the same
+// integer; the edge where the top-digit test and |c| < M / 2 disagree needs |c| >= M / 2 - M / P34).  This kernel uses
+//     gamma_i = r_i (M / P_i)^-1 mod P_i,     c = sum_i gamma_i (M / P_i)  -  k M,     k = round(sum_i gamma_i / P_i)
+// for ANY representatives gamma_i (here in [0, 2 P_i)): per prime and coefficient
+//     acc  += gamma_i * ((M / P_i) mod 2^bits(W))          (wrapping, W-wide)
+//     frac += hi32(gamma_i * floor(2^59 / P_i))            (27 fractional bits: the sum is within 2^-5.9 + 2^-22 of k)
+// (the pointwise product between the transforms is a lazy Montgomery product, acc_mont_lazy: its 2^-32 rides in the same constants)
+// and at the end  out = acc - ((frac + 2^26) >> 27) * (M mod 2^bits(W)).  The factor (M / P_i)^-1 rides in the constants of
+// the inverse transform's last stage next to 1 / n (Bfly::inv_norm: host.hip folds it into F.P[i].n_inv / last_w), so gamma_i
+// IS the transform's lazy output: no canonicalisation, no multiplication.  State per coefficient: one W-wide word and one
+// 32-bit word in registers instead of k - 1 parked residues; LDS holds the exchange buffer only.
+// The residue split is lazy too ([0, 2 P_i): all the first butterfly stage needs): 2^32 = c_i (mod P_i) with c_i < 2^26 for
+// these primes (P_i = 2^30 - d_i, c_i = 4 d_i), so a 64-bit word folds as t = hi c_i + lo < 2^58 (one v_mad_u64_u32),
+// q = hi32((t >> 28) floor(2^60 / P_i)) in {floor(t / P_i) - 1, floor(t / P_i)}, r = lo32(t) - q P_i.
+// Public fwd() / inv() of the plans keep split_kernel / crt_kernel: they take and produce arbitrary canonical residues.
+// ---------------------------------------------------------------------------------------------------------------
+struct AccArgs {
+    uint64_t c_lo[10], c_hi[10];  // (M / P_i) mod 2^128
+    uint64_t m_lo, m_hi;          // M mod 2^128
+    uint32_t f[10];               // floor(2^59 / P_i)
+    uint32_t m60[10];             // floor(2^60 / P_i)
+};
+constexpr int ACC_FRAC_BITS = 27;
+constexpr int ACC_FAM = 3;   // schedule family of the transforms inside native_product_acc (gen_sched.py)
+
+// t < 2^58 -> t mod p in [0, 2p)
+__device__ __forceinline__ uint32_t acc_red58(uint64_t t, uint32_t p, uint32_t m60) {
+    const uint32_t q = __umulhi((uint32_t)(t >> 28), m60);
+    return (uint32_t)mad_box<true>(q, 0u - p, t);   // lo32(t) - q p as ONE v_mad_u64_u32 (asm: hipcc narrows the C++ form to mul_lo + sub)
+}
+// a * b / 2^32 mod p in [0, 2p) for lazy a, b in [0, 4p), p < 2^30 (Montgomery; pinv_neg = -p^-1 mod 2^32): each operand takes one
+// conditional subtraction of 2p (a b < 4 p^2 < 2^62, t + m p < 2^63, u < p^2 / 2^30 + p < 2p) -- seven instructions where the
+// canonical route (two canonicalisations + Barrett, mul_for_inv) takes thirteen.  The factor 2^-32 is undone by the constants of the
+// inverse transform's last stage (host.hip, build_acc_args).
+__device__ __forceinline__ uint32_t acc_mont_lazy(uint32_t a, uint32_t b, const ModParams<uint32_t> &P) {
+    a = umin<uint32_t>(a, a - P.two_p);
+    b = umin<uint32_t>(b, b - P.two_p);
+    const uint64_t t = (uint64_t)a * b;
+    const uint32_t m = (uint32_t)t * P.pinv_neg;
+    return (uint32_t)(((uint64_t)m * P.p + t) >> 32);
+}
+// value mod P_k in [0, 2 P_k) for a u32 / u64 / u128 word
+template <class W> __device__ __forceinline__ uint32_t split30_lazy(W w, const SplitArgs &A, const AccArgs &C, int k) {
+    const uint32_t p = (uint32_t)A.prime[k], c = A.c[k], m60 = C.m60[k];
+    if constexpr (sizeof(W) == 4) {
+        return red32_lazy((uint32_t)w, p, A.one_shoup[k]);
+    } else if constexpr (sizeof(W) == 8) {
+        return acc_red58((uint64_t)(uint32_t)((uint64_t)w >> 32) * c + (uint32_t)w, p, m60);
+    } else {
+        uint32_t r = acc_red58((uint64_t)(uint32_t)(w.hi >> 32) * c + (uint32_t)w.hi, p, m60);   // r < 2^31: r c + limb < 2^58
+        r = acc_red58((uint64_t)r * c + (uint32_t)(w.lo >> 32), p, m60);
+        return acc_red58((uint64_t)r * c + (uint32_t)w.lo, p, m60);
+    }
+}
+
+template <class W> struct AccWord;
+template <> struct AccWord<uint32_t> {
+    using A = uint32_t;
+    static __device__ __forceinline__ A mad(A acc, uint32_t g, uint64_t lo, uint64_t) { return acc + g * (uint32_t)lo; }
+    static __device__ __forceinline__ void pin(A &acc) { asm volatile("" : "+v"(acc)); }
+    static __device__ __forceinline__ uint32_t out(A acc, uint32_t k, uint64_t mlo, uint64_t) { return acc - k * (uint32_t)mlo; }
+};
+template <> struct AccWord<uint64_t> {
+    using A = uint64_t;
+    static __device__ __forceinline__ A mad(A acc, uint32_t g, uint64_t lo, uint64_t) { return acc + (uint64_t)g * lo; }
+    static __device__ __forceinline__ void pin(A &acc) { asm volatile("" : "+v"(acc)); }
+    static __device__ __forceinline__ uint64_t out(A acc, uint32_t k, uint64_t mlo, uint64_t) { return acc - (uint64_t)k * mlo; }
+};
+template <> struct AccWord<Word128> {
+    using A = unsigned __int128;
+    static __device__ __forceinline__ A mad(A acc, uint32_t g, uint64_t lo, uint64_t hi) {
+        return acc + (A)g * (((A)hi << 64) | lo);
+    }
+    static __device__ __forceinline__ void pin(A &acc) {
+        uint64_t l = (uint64_t)acc, h = (uint64_t)(acc >> 64);
+        asm volatile("" : "+v"(l), "+v"(h));
+        acc = ((A)h << 64) | l;
+    }
+    static __device__ __forceinline__ Word128 out(A acc, uint32_t k, uint64_t mlo, uint64_t mhi) {
+        const A r = acc - (A)k * (((A)mhi << 64) | mlo);
+        return Word128{(uint64_t)r, (uint64_t)(r >> 64)};
+    }
+};
+
+// NF_KEEP_L / NF_KEEP_R / NF_TW_CHUNK as native_product
+template <int KIND, int LOGN, int BLK, int OPT>
+__device__ __forceinline__ void native_product_acc(typename NativeShape<KIND>::W *__restrict__ prod,
+                                                   const typename NativeShape<KIND>::W *__restrict__ lhs,
+                                                   const typename NativeShape<KIND>::W *__restrict__ rhs,
+                                                   const FusedTables<NativeShape<KIND>::KP> &F, const SplitArgs &S,
+                                                   const AccArgs &C, uint32_t batch, uint32_t sub0, uint32_t *lds_all) {
+    using SH = NativeShape<KIND>;
+    using W = typename SH::W;
+    using AW = AccWord<W>;
+    using Wf = NttWp<uint32_t, LOGN, false, CLS_LAZY, BLK, ACC_FAM>;   // padded exchange layout: no address arithmetic per access
+    using Wi = NttWp<uint32_t, LOGN, true, CLS_LAZY, BLK, ACC_FAM>;
+    constexpr int E = Wf::E, TPP = Wf::TPP, NPASS = Wf::NPASS, KP = SH::KP;
+    constexpr bool KEEP_L = (OPT & NF_KEEP_L) != 0, KEEP_R = (OPT & NF_KEEP_R) != 0;
+    constexpr int TWC = (OPT & NF_TW_CHUNK) ? 2 : 0;
+    constexpr uint32_t FULL = Wf::FULL, RM0 = Wf::S::RMASK[0];
+    static_assert(RM0 == Wi::S::RMASK[NPASS - 1] && Wf::S::RMASK[NPASS - 1] == Wi::S::RMASK[0],
+                  "forward and inverse schedules must mirror each other");
+    static_assert(2ull * KP * (1ull << ACC_FRAC_BITS) + (1ull << (ACC_FRAC_BITS - 1)) <= (1ull << 32),
+                  "the fraction sum of lazy residues (each below 2 P_i) and its rounding constant fit 32 bits");
+    const uint32_t tid = threadIdx.x & (TPP - 1), pl = threadIdx.x / TPP;
+    uint32_t *lds = lds_all + (size_t)pl * Wf::B::LDS_WORDS_1;
+    const uint32_t sub = sub0 + pl;
+    // operands: workgroup-uniform base + one 32-bit byte offset per thread + the instruction's immediate (ragged tail: the threads of
+    // products past the end recompute the last one and store nothing)
+    const uint32_t plc = sub < batch ? pl : batch - 1 - sub0;
+    const W *lp0 = lhs + ((size_t)sub0 << LOGN), *rp0 = rhs + ((size_t)sub0 << LOGN);
+    auto word_at = [&](const W *base0, int j, uint32_t eb) -> W {
+        const uint32_t cb = cdep((uint32_t)j, RM0) * (uint32_t)sizeof(W), win = cb & ~4095u, imm = cb & 4095u;
+        const char *base = reinterpret_cast<const char *>(base0) + win;
+        return *reinterpret_cast<const W *>(base + (size_t)(((plc << LOGN) + eb) * (uint32_t)sizeof(W)) + imm);
+    };
+    using RW = typename std::conditional<SH::BINARY, uint32_t, W>::type;
+    auto load_rhs = [&](int j, uint32_t eb) -> RW {
+        const W w = word_at(rp0, j, eb);
+        if constexpr (SH::BINARY) {  // `as u32`: src/native_binary64.rs:379-385, src/native_binary128.rs:100-106
+            if constexpr (sizeof(W) == 16) return (uint32_t)w.lo;
+            else return (uint32_t)w;
+        } else {
+            return w;
+        }
+    };
+    W lw[KEEP_L ? E : 1];
+    RW rw[KEEP_R ? E : 1];
+    {
+        const uint32_t ebase = pdep<FULL & ~RM0>(tid);
+        if constexpr (KEEP_L) {
+#pragma unroll
+            for (int j = 0; j < E; ++j) lw[j] = word_at(lp0, j, ebase);
+        }
+        if constexpr (KEEP_R) {
+#pragma unroll
+            for (int j = 0; j < E; ++j) rw[j] = load_rhs(j, ebase);
+        }
+    }
+    typename AW::A acc[E];
+    uint32_t frac[E];
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        acc[j] = 0;
+        frac[j] = 0;
+    }
+    auto one_prime = [&](const int i) {
+        uint32_t a[E], b[E];
+        // offsets of the three transforms recomputed per prime from opaque copies of the thread index: hoisted out of the
+        // prime loop (k x 3 inlined transforms) they would stay live next to the accumulators
+        uint32_t tidf = tid, tidg = tid, tidi = tid;
+        asm volatile("" : "+v"(tidf), "+v"(tidg), "+v"(tidi));
+        const uint32_t eb_l = pdep<FULL & ~RM0>(tidf), eb_r = pdep<FULL & ~RM0>(tidg);
+        // (2p and p copied into VECTOR registers -- plain v_add_u32 / v_sub_u32 on vector operands issue at twice the rate of the
+        // scalar-operand forms in isolation, profiles/r04_ubench3_valu_forms.txt -- made the kernel 5 % SLOWER: tools/native_lab)
+        const ModParams<uint32_t> &Pv = F.P[i];
+#pragma unroll
+        for (int j = 0; j < E; ++j)
+            a[j] = split30_lazy<W>(KEEP_L ? lw[KEEP_L ? j : 0] : word_at(lp0, j, eb_l), S, C, i);
+        __builtin_amdgcn_sched_barrier(0);   // (the phases of a prime, and the primes, kept apart: overlapped they spill)
+        Wf::template pass<0, false, false, false, TWC>(a, lds, tidf, F.twf[i], nullptr, Pv);   // FIN = false: lazy outputs in [0, 4p)
+        Wf::wsync();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            const RW w = KEEP_R ? rw[KEEP_R ? j : 0] : load_rhs(j, eb_r);
+            if constexpr (SH::BINARY) b[j] = w;
+            else b[j] = split30_lazy<W>(w, S, C, i);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        Wf::template pass<0, false, false, false, TWC>(b, lds, tidg, F.twf[i], nullptr, Pv);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < E; ++j) a[j] = acc_mont_lazy(a[j], b[j], Pv);
+        Wf::wsync();
+        __builtin_amdgcn_sched_barrier(0);
+        // FIN = false: the lazy outputs in [0, 2 P_i) are gamma_i (the last stage's constants carry (M / P_i)^-1 / n)
+        Wi::template pass<0, true, false, false, TWC>(a, lds, tidi, F.twi[i], nullptr, Pv);
+        __builtin_amdgcn_sched_barrier(0);
+        const uint64_t clo = C.c_lo[i], chi = C.c_hi[i];
+        const uint32_t fi = C.f[i];
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            acc[j] = AW::mad(acc[j], a[j], clo, chi);
+            frac[j] += __umulhi(a[j], fi);
+            // (opaque: left alone hipcc sinks the whole sum to the final store and keeps -- spills -- the k residue tiles instead
+            // of the accumulators, i.e. re-invents the parking this kernel exists to avoid)
+            AW::pin(acc[j]);
+            asm volatile("" : "+v"(frac[j]));
+        }
+        Wf::wsync();  // the exchange buffer is reused by the next prime
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    if constexpr ((OPT & NF_ROLL) != 0) {
+        // the primes as a RUNTIME loop: one copy of the three transforms (tables and constants of prime i by scalar loads from the
+        // kernel arguments) -- a k-th of the code
+#pragma clang loop unroll(disable)
+        for (int i = 0; i < KP; ++i) one_prime(i);
+    } else {
+        static_for<0, KP>([&](auto ic) { one_prime(ic.value); });
+    }
+    // the output addresses from an opaque copy of the thread index: computed at the top of the kernel (where hipcc would put them)
+    // they are sixteen 64-bit values that live -- spilled -- through all k primes
+    uint32_t tx = threadIdx.x;
+    asm volatile("" : "+v"(tx));
+    const uint32_t subo = sub0 + tx / TPP;
+    if (subo < batch) {
+        W *op = prod + ((size_t)subo << LOGN);
+        const uint32_t ebo = pdep<FULL & ~RM0>(tx & (TPP - 1));
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            const uint32_t k = (frac[j] + (1u << (ACC_FRAC_BITS - 1))) >> ACC_FRAC_BITS;
+            op[ebo | cdep((uint32_t)j, RM0)] = AW::out(acc[j], k, C.m_lo, C.m_hi);
+        }
+    }
+}
+
+template <int KIND, int LOGN, int BLK, int WPS, int OPT>
+__global__ __launch_bounds__(BLK, WPS) void native_polymul_kernel_acc(typename NativeShape<KIND>::W *__restrict__ prod,
+                                                                  const typename NativeShape<KIND>::W *__restrict__ lhs,
+                                                                  const typename NativeShape<KIND>::W *__restrict__ rhs,
+                                                                  const FusedTables<NativeShape<KIND>::KP> F,
+                                                                  const SplitArgs S, const AccArgs C, uint32_t batch) {
+    using Wf = NttWp<uint32_t, LOGN, false, CLS_LAZY, BLK, ACC_FAM>;
+    constexpr int PPB = BLK / Wf::TPP;
+    static_assert(BLK % Wf::TPP == 0 && PPB >= 1, "whole products per workgroup");
+    __shared__ __attribute__((aligned(16))) uint32_t lds_all[(size_t)PPB * Wf::B::LDS_WORDS_1];
+    native_product_acc<KIND, LOGN, BLK, OPT>(prod, lhs, rhs, F, S, C, batch, blockIdx.x * PPB, lds_all);
+}
+
 // products per workgroup / parked words per workgroup of a shape
 template <int KIND, int LOGN, int BLK> struct NativeTile {
     using Wf = NttWp<uint32_t, LOGN, false, CLS_LAZY, BLK, 1>;

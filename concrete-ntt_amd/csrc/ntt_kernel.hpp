@@ -348,6 +348,16 @@ struct NttKernel {
         }
     }
 
+    // Table entry toff + c (c: the register part of the index, a compile-time constant after unrolling) as
+    //     [uniform base + 4 KiB window of c: scalar add] + [32-bit byte offset of toff: one VGPR] + [rest of c: the instruction's immediate]
+    // -- the saddr form of global_load.  Written as tw + (toff + c) * 8 the constant sits inside the zero-extended product, hipcc
+    // builds a 64-bit VGPR address per load (v_lshl_add_u64 / v_add_co / v_addc: ~3 VALU instructions per twiddle of every kernel
+    // that reads its twiddles from global memory).
+    static __device__ __forceinline__ TwPair<T> tw_at(const TwPair<T> *__restrict__ tw, uint32_t toff, uint32_t c) {
+        const uint32_t cb = c * (uint32_t)sizeof(TwPair<T>), win = cb & ~4095u, imm = cb & 4095u;
+        const char *base = reinterpret_cast<const char *>(tw) + win;
+        return *reinterpret_cast<const TwPair<T> *>(base + (size_t)(toff * (uint32_t)sizeof(TwPair<T>)) + imm);
+    }
     // one chunk of a stage's twiddles: CH consecutive values of h (the register bits above the stage bit)
     template <int K, int GI, bool IMG, int CH>
     static __device__ __forceinline__ void stage_twiddles(TwPair<T> (&w)[CH], int h0, uint32_t toff, uint32_t tid, const TwPair<T> *img,
@@ -360,9 +370,8 @@ struct NttKernel {
             const int h = h0 + hh;
             if constexpr (IMG && !g.uniform)
                 w[hh] = img[img_off(K, GI) + h * g.d + (tid >> g.shift)];
-            else  // uniform table base + 32-bit byte offset: the saddr form of global_load, no 64-bit VGPR address
-                w[hh] = *reinterpret_cast<const TwPair<T> *>(
-                    reinterpret_cast<const char *>(tw) + (toff + (cdep((uint32_t)h << (k + 1), RM) >> (b + 1))) * (uint32_t)sizeof(TwPair<T>));
+            else
+                w[hh] = tw_at(tw, toff, cdep((uint32_t)h << (k + 1), RM) >> (b + 1));
         }
     }
     // the butterflies of the stage whose twiddle index h lies in [h0, h0 + CH)
@@ -455,10 +464,8 @@ struct NttKernel {
                     const int h = h0 + hh;
                     if constexpr (IMG && !g.uniform)
                         w[hh] = img[img_off(K, GI) + h * g.d + (tid >> g.shift)];
-                    else  // uniform table base + 32-bit byte offset: the saddr form of global_load, no 64-bit VGPR address
-                        w[hh] = *reinterpret_cast<const TwPair<T> *>(
-                            reinterpret_cast<const char *>(tw) +
-                            (toff + (cdep((uint32_t)h << (k + 1), RM) >> (b + 1))) * (uint32_t)sizeof(TwPair<T>));
+                    else
+                        w[hh] = tw_at(tw, toff, cdep((uint32_t)h << (k + 1), RM) >> (b + 1));
                 }
 #pragma unroll
                 for (int j = 0; j < E; ++j) {

@@ -66,6 +66,7 @@ inline hipError_t launch_ext_ntt(int logn, int cls, T *out, const T *terms, cons
 // otherwise.  `tables` points to the FusedTables<KP> of the plan (native_fused.hpp); KIND = cntt_native_kind_t value.
 struct SplitArgs;
 struct CrtArgs;
+struct AccArgs;
 struct ProductArgs;
 // product::Plan with two u32 primes of one arithmetic class `cls`, 32 <= n <= 4096 (product_fused.hpp): forward
 // (flag = FwdMode::Bounded applies) or inverse (flag = InvMode::Accumulate) in one kernel; `tables` points to a
@@ -75,9 +76,17 @@ hipError_t launch_product_fused2(int logn, int cls, bool inv, uint64_t *standard
 // The persistent form of the kernel (n = 16384 / 32768 of every kind, n = 8192 of the kinds that do not fit LDS there, native128 =
 // kind 2 at every size) parks residue
 // tiles in `scratch` (native_fused_scratch_words() 32-bit words); the other shapes ignore it.
+// `acc` (round 4): constants of the accumulating CRT and `tables_acc`, the FusedTables whose last-stage constants carry
+// (M / P_i)^-1 / n -- the sizes that have the register-resident kernel (native_fused_acc()) run it unless CNTT_NATIVE_ACC=0.
 template <int KIND>
 hipError_t launch_native_fused(int logn, void *prod, const void *lhs, const void *rhs, const void *tables, const SplitArgs &S,
-                               const CrtArgs &C, uint32_t batch, uint32_t *scratch, hipStream_t st);
+                               const CrtArgs &C, uint32_t batch, uint32_t *scratch, hipStream_t st, const AccArgs *acc,
+                               const void *tables_acc);
+// sizes / kinds of native_polymul_kernel_acc (no workspace, no parking)
+constexpr bool native_fused_acc(int kind, int logn) {
+    return (kind == 0 || kind == 1 || kind == 3 || kind == 4) && logn >= 5 && logn <= 12;
+}
+bool native_acc_enabled();
 inline int device_num_cus() {
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 256;
@@ -86,6 +95,7 @@ inline int device_num_cus() {
 }
 constexpr bool native_fused_lds13(int kind) { return kind == 0 || kind == 1 || kind == 4; }  // n = 8192 with the tiles in LDS (native_fused_inst.inc)
 inline bool native_fused_persistent(int kind, int logn) {
+    if (native_fused_acc(kind, logn) && native_acc_enabled()) return false;
     return (logn == 13 && !native_fused_lds13(kind)) || logn == 14 || logn == 15 || (kind == 2 && logn >= 5 && logn <= 12);
 }
 // words of one residue tile of a workgroup (256 threads x 16 coefficients hold 4096 / n products below n = 4096)
