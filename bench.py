@@ -202,6 +202,76 @@ class Timer:
         return e0.elapsed_time(e1) / reps
 
 
+class Sensors:
+    """Shader clock and package power of the GPU under test, sampled from a thread while the timed regions run (VERDICT round 3:
+    the line must show whether a slow number is a slow box or a slow build).  Source: the amdgpu hwmon files of the card whose PCI
+    address torch reports for the device (freq1_input = sclk in Hz, power1_input = package power in microwatts) -- plain file
+    reads, no subprocess; falls back to amdsmi's python binding, then to nothing (fields null)."""
+
+    def __init__(self, torch, dev_index, period_s=0.01):
+        import threading
+        self.period, self.samples, self.phase, self.source = period_s, [], None, None
+        self._read = None
+        try:
+            pr = torch.cuda.get_device_properties(dev_index)
+            bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, getattr(pr, "pci_device_id", 0))
+            import glob
+            for card in glob.glob("/sys/class/drm/card*"):
+                d = os.path.join(card, "device")
+                if os.path.basename(os.path.realpath(d)) != bdf:
+                    continue
+                for h in glob.glob(os.path.join(d, "hwmon", "hwmon*")):
+                    f, w = os.path.join(h, "freq1_input"), os.path.join(h, "power1_input")
+                    if os.path.exists(f) and os.path.exists(w):
+                        int(open(f).read()), int(open(w).read())
+                        self._read = lambda f=f, w=w: (int(open(f).read()) / 1e6, int(open(w).read()) / 1e6)
+                        self.source = "sysfs hwmon %s (freq1_input, power1_input)" % bdf
+                if self._read:
+                    break
+        except Exception:
+            self._read = None
+        if self._read is None:
+            try:
+                import amdsmi
+                amdsmi.amdsmi_init()
+                h = amdsmi.amdsmi_get_processor_handles()[dev_index]
+
+                def rd():
+                    pw = amdsmi.amdsmi_get_power_info(h)
+                    ck = amdsmi.amdsmi_get_clock_info(h, amdsmi.AmdSmiClkType.GFX)
+                    return float(ck["clk"]), float(pw.get("current_socket_power", pw.get("socket_power")))
+                rd()
+                self._read, self.source = rd, "amdsmi (current_socket_power, gfx clk)"
+            except Exception:
+                self._read = None
+        self._stop = threading.Event()
+        self._thread = None
+        if self._read is not None:
+            self._thread = threading.Thread(target=self._loop, daemon=True)
+            self._thread.start()
+
+    def _loop(self):
+        while not self._stop.is_set():
+            ph = self.phase
+            if ph is not None:
+                try:
+                    mhz, w = self._read()
+                    self.samples.append((ph, mhz, w))
+                except Exception:
+                    pass
+            time.sleep(self.period)
+
+    def stop(self):
+        self._stop.set()
+
+    def summary(self, phase):
+        v = [(m, w) for ph, m, w in self.samples if ph == phase]
+        if not v:
+            return {"sclk_mhz": None, "power_w": None, "samples": 0}
+        return {"sclk_mhz": round(sum(m for m, _ in v) / len(v), 1), "power_w": round(sum(w for _, w in v) / len(v), 1),
+                "sclk_mhz_min": min(m for m, _ in v), "power_w_max": max(w for _, w in v), "samples": len(v)}
+
+
 def pmc_traffic(kernel_key, batch, lib_hash):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json, written by
     tools/profile.sh: FETCH_SIZE doubled for gfx950 + WRITE_SIZE, MI355X_MICROARCH.md section HBM).  The passes run the
@@ -220,12 +290,25 @@ def pmc_traffic(kernel_key, batch, lib_hash):
         return None, None, None
 
 
-def extra_configs(args, torch, cntt, timer, rank, world, dist, dev):
+def extra_configs(args, torch, cntt, timer, rank, world, dist, dev, out=None, state=None, sensors=None):
     """The other BASELINE.json configs, timed after the headline region (HIP events, steady-state clocks):
     C3 native64 N=4096, C5 native_binary64 N=2048 (N=1 only), C4 prime64 N=16384 shard-resident (every rank) and --
     with more than one rank -- C4 end to end: scatter from rank 0, transform, gather back."""
     from concrete_ntt_amd import native64, native_binary64, prime64, shard
-    out = []
+    out = [] if out is None else out          # filled in place: the watchdog prints what is there if a later leg hangs
+    state = {} if state is None else state    # {"phase": name of the running leg, "since": perf_counter when it started}
+
+    def enter(phase):
+        state["phase"], state["since"] = phase, time.perf_counter()
+        if sensors is not None:
+            sensors.phase = phase
+
+    def sensed(phase):
+        if sensors is not None:
+            sensors.phase = None
+            sm = sensors.summary(phase)
+            return {"sclk_mhz": sm["sclk_mhz"], "power_w": sm["power_w"]}
+        return {}
 
     def native_case(name, cls, n, batch, binary):
         plan = cls.try_new(n)
@@ -237,11 +320,15 @@ def extra_configs(args, torch, cntt, timer, rank, world, dist, dev):
         if binary:
             rhs &= 1
         plan.reserve(batch)
-        ms = timer.ms(lambda: plan.negacyclic_polymul_batch(prod, lhs, rhs), 5, ramp_s=0.5)
+        timer.ramp(lambda: plan.negacyclic_polymul_batch(prod, lhs, rhs), 0.5)
+        enter(name)
+        ms = timer.ms(lambda: plan.negacyclic_polymul_batch(prod, lhs, rhs), 20)
         by = 3 * n * 8 * batch
-        out.append({"config": name, "workload": "%s negacyclic_polymul N=%d batch=%d, device-resident" % (name, n, batch),
-                    "ms_per_batch": ms, "value": batch / (ms * 1e-3), "unit": "polymul/s",
-                    "algorithmic_bytes": by, "roofline_frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
+        e = {"config": name, "workload": "%s negacyclic_polymul N=%d batch=%d, device-resident" % (name, n, batch),
+             "ms_per_batch": ms, "value": batch / (ms * 1e-3), "unit": "polymul/s",
+             "algorithmic_bytes": by, "roofline_frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        e.update(sensed(name))
+        out.append(e)
         del lhs, rhs, prod, plan
 
     if world == 1 and not args.no_extra:
@@ -262,8 +349,14 @@ def extra_configs(args, torch, cntt, timer, rank, world, dist, dev):
         a = torch.empty(per_gpu * n4, dtype=torch.int64, device=dev)
         cntt.fill_uniform(a, P62, 0x5EED0004 + rank * per_gpu * n4)
         reps = 3
-        fwd_ms = timer.ms(lambda: plan.fwd_batch(a), reps, ramp_s=0.3)
+        timer.ramp(lambda: plan.fwd_batch(a), 0.3)
+        enter("C4 fwd")
+        fwd_ms = timer.ms(lambda: plan.fwd_batch(a), reps)
+        s_f = sensed("C4 fwd")
+        enter("C4 inv")
         inv_ms = timer.ms(lambda: plan.inv_batch(a), reps)
+        s_i = sensed("C4 inv")
+        enter("C4 max over ranks")
         t = torch.tensor([fwd_ms, inv_ms], dtype=torch.float64)
         if dist is not None:
             t = t.to(dev) if args.dist_backend == "nccl" else t
@@ -277,10 +370,26 @@ def extra_configs(args, torch, cntt, timer, rank, world, dist, dev):
                     "fwd_ms": fwd_ms, "inv_ms": inv_ms,
                     "value": world * 2 * per_gpu / ((fwd_ms + inv_ms) * 1e-3), "unit": "NTT/s", "n_gpus": world,
                     "fwd_roofline_frac": by / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                    "inv_roofline_frac": by / (inv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
+                    "inv_roofline_frac": by / (inv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "fwd_sclk_mhz": s_f.get("sclk_mhz"), "fwd_power_w": s_f.get("power_w"),
+                    "inv_sclk_mhz": s_i.get("sclk_mhz"), "inv_power_w": s_i.get("power_w")})
         if dist is not None:
-            # end to end: the whole batch starts and ends on rank 0
-            total = world * per_gpu
+            # end to end: the whole batch starts and ends on rank 0, which holds the batch AND its own shard twice (the scattered
+            # copy and the gather's staging): check the budget first and shrink the leg instead of failing in hipMalloc
+            enter("C4 end to end: memory budget")
+            del a
+            torch.cuda.empty_cache()
+            free_b, _ = torch.cuda.mem_get_info(dev)
+            ft = torch.tensor([float(free_b)], dtype=torch.float64)
+            ft = ft.to(dev) if args.dist_backend == "nccl" else ft
+            dist.all_reduce(ft, op=dist.ReduceOp.MIN)
+            free_min = float(ft.cpu()[0])
+            e2e_per_gpu, shrunk = per_gpu, False
+            while e2e_per_gpu > 1 and (world + 3) * e2e_per_gpu * n4 * 8 > 0.9 * free_min:
+                e2e_per_gpu //= 2
+                shrunk = True
+            a = torch.empty(0, dtype=torch.int64, device=dev)
+            total = world * e2e_per_gpu
             full = None
             if rank == 0:
                 full = torch.empty(total * n4, dtype=torch.int64, device=dev)
@@ -295,16 +404,20 @@ def extra_configs(args, torch, cntt, timer, rank, world, dist, dev):
 
             for it in range(2):   # first pass creates the point-to-point channels; the second is the one reported
                 fence()
+                enter("C4 end to end pass %d: scatter" % it)
                 t0 = time.perf_counter()
                 mine = shard.scatter_batch(full, n4, src=0)
                 fence()
+                enter("C4 end to end pass %d: fwd" % it)
                 t1 = time.perf_counter()
                 plan.fwd_batch(mine)
                 fence()
+                enter("C4 end to end pass %d: gather" % it)
                 t2 = time.perf_counter()
                 got = shard.gather_batch(mine, n4, total, dst=0, out=full if rank == 0 else None)
                 fence()
                 t3 = time.perf_counter()
+                state.setdefault("done", []).append({"pass": it, "scatter_s": t1 - t0, "compute_s": t2 - t1, "gather_s": t3 - t2})
                 del mine, got
             tt = torch.tensor([t1 - t0, t2 - t1, t3 - t2], dtype=torch.float64)
             tt = tt.to(dev) if args.dist_backend == "nccl" else tt
@@ -315,12 +428,16 @@ def extra_configs(args, torch, cntt, timer, rank, world, dist, dev):
                                     % (total, total * n4 * 8 / 2**30, world),
                         "scatter_s": sc, "compute_s": co, "gather_s": ga,
                         "value": total / (sc + co + ga), "unit": "NTT/s (end to end, one fwd per polynomial)",
-                        "compute_only_value": total / co, "n_gpus": world})
+                        "compute_only_value": total / co, "n_gpus": world,
+                        "polynomials_per_gpu": e2e_per_gpu, "shrunk_to_fit_rank0_memory": shrunk})
             del full
         del a
     except Exception as e:
         out.append({"config": "C4 prime64 N=16384", "error": repr(e)})
     torch.cuda.empty_cache()
+    enter("done")
+    if sensors is not None:
+        sensors.phase = None
     return out
 
 
@@ -420,27 +537,33 @@ def run_rank(args):
 
     # device clock ramp (untimed): the GPU idles at ~100 MHz and the package power controller needs
     # hundreds of milliseconds of sustained load to settle (profiles/r01_power_clock_lab.txt)
+    sensors = Sensors(torch, local_rank)
     timer.ramp(step, args.ramp_seconds)
     for _ in range(args.warmup):
         step()
     fence()
+    sensors.phase = "timed"
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    sensors.phase = None
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     # the same step as three API-faithful launches (fwd, mul_assign_normalize, inv), for reference
+    timer.ramp(step_unfused, 0.3)   # its own steady state: three kernels with different power draw alternate
     fence()
+    sensors.phase = "unfused"
     t1 = time.perf_counter()
     for _ in range(args.steps):
         step_unfused()
     fence()
     unfused = time.perf_counter() - t1
+    sensors.phase = None
     if dist is not None:
         t = torch.tensor([unfused], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -448,10 +571,19 @@ def run_rank(args):
 
     # per-kernel timing with HIP events on the launch stream (roofline leg), after the timed region
     reps = 50
-    fused_ms = timer.ms(step, reps)
-    fwd_ms = timer.ms(lambda: plan.fwd_batch(a), reps)
-    inv_ms = timer.ms(lambda: plan.inv_batch(a), reps)
-    mul_ms = timer.ms(lambda: plan.mul_assign_normalize_batch(a, b), reps)
+
+    def kernel_ms(tag, fn):   # ~0.3 s of back-to-back launches first: the sensors see the kernel's own steady state
+        timer.ramp(fn, 0.3)
+        est = timer.ms(fn, 10)
+        n = max(reps, int(60.0 / max(est, 1e-3)) + 1)    # at least 60 ms under the sensors (10 ms sampling period)
+        sensors.phase = tag
+        ms = timer.ms(fn, n)
+        sensors.phase = None
+        return ms
+    fused_ms = kernel_ms("fused", step)
+    fwd_ms = kernel_ms("fwd", lambda: plan.fwd_batch(a))
+    inv_ms = kernel_ms("inv", lambda: plan.inv_batch(a))
+    mul_ms = kernel_ms("pointwise", lambda: plan.mul_assign_normalize_batch(a, b))
     alg_bytes = 2 * N * 8 * batch                     # 2*N*sizeof(T) = 16384 B per transform
     # Dominant kernel of the timed region = the fused step kernel (2 transforms per polynomial per launch).  It moves
     # 3*N*8 bytes per polynomial -- read lhs, read rhs_ntt, write lhs -- and THAT is what roofline.achieved / frac are
@@ -486,6 +618,9 @@ def run_rank(args):
                        "rccl_ranks": world if (dist is not None and args.dist_backend == "nccl") else 0},
             "per_gpu_value": units / elapsed / world,
             "unfused_value": units / unfused, "unfused_ms_per_step": 1e3 * unfused / args.steps,
+            # the three kernels of the unfused step timed alone, each at its own steady-state clock (roofline.sensors): the step
+            # alternates them, so its time is their sum at the clock the MIX settles at -- no launch gap (tools/trace_gaps.py)
+            "unfused_kernel_sum_ms": fwd_ms + inv_ms + mul_ms,
             "fwd_inv_standalone_value": world * 2 * batch / ((fwd_ms + inv_ms) * 1e-3),   # API-faithful fwd + inv launches, NTT/s
             "roofline": {"bound": "valu/power", "priced_against": "hbm",
                          "kernel": "mul_kernel_wp<u64, LOGN=10, lazy> (fwd + pointwise + inv fused)",
@@ -502,8 +637,15 @@ def run_rank(args):
                          "fwd_kernel_ms": fwd_ms, "fwd_frac": alg_bytes / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "inv_kernel_ms": inv_ms, "inv_frac": alg_bytes / (inv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "pointwise_kernel_ms": mul_ms,
-                         "pointwise_frac": 3 * N * 8 * batch / (mul_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                         "pointwise_frac": 3 * N * 8 * batch / (mul_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         # shader clock / package power while the timed region ran (a slow box shows here, not in the build)
+                         "sclk_mhz": sensors.summary("timed")["sclk_mhz"], "power_w": sensors.summary("timed")["power_w"],
+                         "sensors": {"source": sensors.source, "period_s": sensors.period, "timed_region": sensors.summary("timed"),
+                                     "unfused_step": sensors.summary("unfused"),
+                                     "fused_kernel": sensors.summary("fused"), "fwd_kernel": sensors.summary("fwd"),
+                                     "inv_kernel": sensors.summary("inv"), "pointwise_kernel": sensors.summary("pointwise")}},
             "configs": extras,
+            "extras_watchdog": any("watchdog" in str(c.get("error", "")) for c in extras),
         }
         if world == 1 and not args.no_cpu_baseline and with_cpu_baseline:
             try:
@@ -525,22 +667,36 @@ def run_rank(args):
             return
         write_line(extras, with_cpu_baseline)
 
+    extras, xstate = [], {}
+
     def on_timeout():
-        sys.stderr.write("bench.py rank %d: extras still running after %d s -- watchdog\n" % (rank, args.extras_timeout))
-        emit([{"config": "extras", "error": "not finished after %d s (watchdog); the headline numbers above were complete"
-                                            % args.extras_timeout}], with_cpu_baseline=False)
-        os._exit(0)
+        # what finished stays on the line; the entry says which leg was running and for how long (per-phase seconds of an
+        # end-to-end pass that completed are under `phases_done`)
+        since = xstate.get("since")
+        sys.stderr.write("bench.py rank %d: extras still running after %d s (in %r) -- watchdog\n"
+                         % (rank, args.extras_timeout, xstate.get("phase")))
+        emit(list(extras) + [{"config": "extras", "error": "not finished after %d s (watchdog); the headline numbers above were "
+                                                           "complete" % args.extras_timeout,
+                              "running_phase": xstate.get("phase"),
+                              "seconds_in_phase": (time.perf_counter() - since) if since else None,
+                              "phases_done": xstate.get("done", [])}], with_cpu_baseline=False)
+        # Status: 0 by default -- the line is complete and says so itself (top-level "extras_watchdog": true and the entry above);
+        # a non-zero status would make a launcher (torch.distributed.run, the driver) discard a valid headline because a leg
+        # AFTER the timed region hung.  --extras-strict turns the hang into status 3 for callers that want it loud.
+        os._exit(3 if args.extras_strict else 0)
 
     watchdog = threading.Timer(args.extras_timeout, on_timeout)
     watchdog.daemon = True
     watchdog.start()
-    extras = []
     try:
-        extras = extra_configs(args, torch, cntt, timer, rank, world, dist, dev)
+        extra_configs(args, torch, cntt, timer, rank, world, dist, dev, out=extras, state=xstate, sensors=sensors)
     except Exception as e:
-        extras = [{"config": "extras", "error": repr(e)}]
+        extras.append({"config": "extras", "error": repr(e), "running_phase": xstate.get("phase")})
     watchdog.cancel()
+    sensors.stop()
     emit(extras)
+    if watchdog.is_alive():
+        watchdog.join(timeout=1.0)   # a timer that already fired is finishing its write: never close the descriptor under it
     os.close(json_fd)
     if dist is not None:
         dist.barrier()
@@ -569,6 +725,8 @@ def main():
     ap.add_argument("--dry-run", action="store_true",
                     help="launch / rendezvous plumbing only (gloo, no GPU, no transform); prints a line with value null")
     ap.add_argument("--launch-timeout", type=int, default=1500, help="seconds the launcher waits for its ranks")
+    ap.add_argument("--extras-strict", action="store_true",
+                    help="exit with status 3 (instead of 0) when the extras watchdog fires")
     ap.add_argument("--extras-timeout", type=int, default=420,
                     help="seconds the extras (C3 / C4 / C5 legs after the timed region) may take before a watchdog prints the "
                          "line without them")

@@ -9,7 +9,19 @@ from ._lib import Panic, buffer_info, check, lib
 
 class PrimePlan:
     """Negacyclic NTT plan for a prime modulus; mirrors concrete_ntt::prime{32,64}::Plan
-    (src/prime64.rs:221-236, :701-1129 ; src/prime32.rs:601-616, :627-927)."""
+    (src/prime64.rs:221-236, :701-1129 ; src/prime32.rs:601-616, :627-927).
+
+    INPUT CONTRACT (include/cntt.h): every coefficient handed to fwd / inv / the pointwise calls is canonical, 0 <= x < modulus --
+    what the reference's own tests feed and the only range on which its back ends agree with each other.  The
+    kernels rely on it (the lazy classes skip the first stage's conditional subtraction); words >= modulus are NOT rejected and
+    NOT reduced: the call completes and the affected outputs are unspecified residues (tests/test_gpu_parity.py pins exactly
+    that: no fault, canonical inputs of the same batch unaffected).  `check_canonical(buf)` below validates a host array."""
+
+    def check_canonical(self, buf):
+        """Raise Panic if a host array holds a word >= modulus (the transforms do not check: see the class docstring)."""
+        a = np.asarray(buf)
+        if a.size and int(a.max()) >= self.modulus():
+            raise Panic("coefficient %d >= modulus %d: outside the transforms' input contract" % (int(a.max()), self.modulus()))
 
     BITS = 64
 

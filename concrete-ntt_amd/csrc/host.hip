@@ -437,6 +437,25 @@ template <class T> static int mul_ntt_device(const PrimePlan<T> *pl, T *lhs, con
     return ntt_device<T>(pl, lhs, batch, true, st);
 }
 
+// Three / four outputs of the fused mul_accumulate chain where only the one- / two-output kernels exist (64-bit words at n = 16384,
+// 32-bit words at n = 32768): two fused launches of <= 2 outputs against the composed path, measured per class with J = 6
+// (profiles/r04_chain_split.jsonl, ms per 1024 elements, split / composed):
+//   u64 n = 16384   p < 2^50 (doubles)  0.99 / 1.48, 1.12 / 1.61     2^64 - c  1.77 / 2.00, 1.98 / 2.31     -> split
+//                   62-bit  1.74 / 1.61, 1.98 / 1.88     63-bit  1.87 / 1.70, 2.16 / 1.99                     -> composed
+//   u32 n = 32768   30-bit  1.45 / 1.61, 1.73 / 1.94                                                          -> split
+//                   31-bit  1.70 / 1.75, 2.01 / 1.97     p >= 2^31 (doubles)  2.14 / 2.07, 2.58 / 2.48        -> composed
+// CNTT_EXT_SPLIT=0 never splits, =1 always does (A/B runs); the decision of the call in flight sits in a thread-local because
+// launch_ext_ntt() (ntt_launch.hpp) only asks ext_split_enabled().
+static thread_local bool g_ext_split_wins = true;
+static bool ext_split_wins(size_t word, int logn, int cls) {
+    if (word == 8 && logn == 14) return cls == CLS_FP || cls == CLS_FP51 || cls == CLS_PM64;
+    if (word == 4 && logn == 15) return cls == CLS_LAZY;
+    return true;
+}
+bool cntt::ext_split_enabled() {
+    static const int mode = [] { const char *e = std::getenv("CNTT_EXT_SPLIT"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+    return mode < 0 ? g_ext_split_wins : mode == 1;
+}
 // mul_accumulate chain: out[b][o] (+)= inv(sum_j fwd(terms[b][j]) . key_ntt[j][o])  (device pointers).
 // Fused kernel when the transform lives in one wavefront group and nout <= 4; otherwise composed from the batched
 // kernels through a stream-ordered scratch allocation.
@@ -453,6 +472,7 @@ static int external_product_device(const PrimePlan<T> *pl, T *out, const T *term
     DeviceTables<T> t;
     if (int rc = device_tables(pl, &t)) return rc;
     const int tcls = transform_class(pl);
+    g_ext_split_wins = ext_split_wins(sizeof(T), pl->logn, tcls);
     const hipError_t e = launch_ext_ntt<T>(pl->logn, tcls, out, terms, key, alt_tables(tcls) ? t.fwd_fp : t.fwd,
                                            alt_tables(tcls) ? t.inv_fp : t.inv, pl->mp, (uint32_t)batch, (uint32_t)nterms,
                                            (uint32_t)nout, accumulate, st);
@@ -1037,8 +1057,10 @@ static size_t native_park_bytes(const cntt_native *pl, size_t batch) {
 static size_t native_workspace_bytes(const cntt_native *pl, size_t batch) {
     const size_t park = native_park_bytes(pl, batch);
     if (park) return park;
-    // the LDS-parked whole-product kernel (32 <= n <= 4096, every fused kind but native128) needs no workspace at all
-    if (native_fusable(pl, batch) && pl->p32[0]->logn >= 5 && pl->p32[0]->logn <= 12) return 0;
+    // the register-resident whole-product kernel (accumulating CRT) and the LDS-parked one (32 <= n <= 4096, every fused kind but
+    // native128) need no workspace at all
+    if (native_fusable(pl, batch) && pl->has_acc && native_fused_acc((int)pl->kind, pl->p32[0]->logn) && native_acc_enabled()) return 0;
+    if (native_fusable(pl, batch) && pl->p32[0]->logn >= 5 && pl->p32[0]->logn <= 12 && pl->kind != CNTT_NATIVE128_PLAN32) return 0;
     return 2 * (size_t)pl->info.nprimes * batch * pl->n * pl->rbytes();
 }
 // caller holds pl->cache->mu

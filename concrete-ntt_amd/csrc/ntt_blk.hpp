@@ -18,16 +18,8 @@
 #pragma once
 #include "ntt_kernel.hpp"
 
-// Timing-only ablations for tools/blk_lab.hip (results are wrong with any bit set; the library never defines it):
-//   1: no workgroup barriers   2: every twiddle from table entry 1 (no thread-dependent loads)   4: no prefetch
-//   8: no LDS exchanges   16: no HBM loads / stores   32: no HBM stores (loads kept)   64: every load from the first 256 polynomials (cache-resident)
-#ifndef CNTT_BLK_LAB
-#define CNTT_BLK_LAB 0
-#endif
-// phase stamps of the timing lab (tools/blk_lab.hip defines it; nothing in the library)
-#ifndef CNTT_BLK_STAMP
-#define CNTT_BLK_STAMP(k)
-#endif
+// (The timing-only ablation switches and phase stamps of tools/blk_lab.hip are NOT in this header: tools/blk_lab.sh applies
+// tools/blk_lab.patch to a scratch copy.)
 
 namespace cntt {
 
@@ -42,13 +34,8 @@ struct NttBlk {
     static constexpr uint32_t FULL = B::FULL;
     static constexpr uint32_t BLK_IO = 0x381u;  // a wavefront's block, 16 bytes per lane on consecutive addresses
     static constexpr uint32_t RM0 = S::RMASK[0], RM1 = S::RMASK[1], RM2 = S::RMASK[2], RM3 = S::RMASK[3];
-#ifdef CNTT_BLK_DIRECT_IO   // lab: HBM accessed in the block pass's own register layout (64 B per lane), no LDS transpose
-    static constexpr uint32_t LOAD_RM = RM0;
-    static constexpr uint32_t STORE_RM = RM3;
-#else
     static constexpr uint32_t LOAD_RM = INV ? BLK_IO : RM0;   // HBM layouts: the top pass reads / writes its own layout
     static constexpr uint32_t STORE_RM = INV ? RM3 : BLK_IO;
-#endif
     static constexpr int HARD = INV ? 2 : 0;                  // the exchange after this pass crosses wavefronts
     static_assert(((INV ? RM0 : RM3) & ~0x3ffu) == 0 && ((INV ? RM3 : RM0) >> 10) == (FULL >> 10), "block passes / top pass");
 
@@ -61,7 +48,7 @@ struct NttBlk {
             asm volatile("" ::: "memory");
         } else {  // raw barrier behind an LDS-only wait: __syncthreads() would drain the prefetched global loads too
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if constexpr (!(CNTT_BLK_LAB & 1)) __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         }
     }
@@ -77,17 +64,10 @@ struct NttBlk {
                 constexpr uint32_t BYTE = cdep((uint32_t)(JV * NV), RM) * (uint32_t)sizeof(T);
                 constexpr uint32_t WIN = BYTE & ~4095u, IMM = BYTE & 4095u;
                 const char *base = reinterpret_cast<const char *>(tile) + WIN;
-#ifdef CNTT_BLK_NT
-                if constexpr (NV == 2)
-                    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3 nt" : "=v"(v[JV]) : "v"(voff), "s"(base), "n"(IMM) : "memory");
-                else
-                    asm volatile("global_load_dwordx2 %0, %1, %2 offset:%3 nt" : "=v"(v[JV]) : "v"(voff), "s"(base), "n"(IMM) : "memory");
-#else
                 if constexpr (NV == 2)
                     asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(v[JV]) : "v"(voff), "s"(base), "n"(IMM) : "memory");
                 else
                     asm volatile("global_load_dwordx2 %0, %1, %2 offset:%3" : "=v"(v[JV]) : "v"(voff), "s"(base), "n"(IMM) : "memory");
-#endif
                 issue<JV + 1>(v, tile, voff);
             }
         }
@@ -120,19 +100,15 @@ struct NttBlk {
     static __device__ __forceinline__ void stages(T (&r)[E], uint32_t tidv, const TwPair<T> *__restrict__ tw, const ModParams<T> &P,
                                                   uint32_t qpre = 0u) {
         constexpr uint32_t CM = FULL & ~S::RMASK[K];
-        if constexpr (CNTT_BLK_LAB & 2) {
-            B::template stages<K, 0, false, NORM, TWC>(r, 0u, 0u, 0u, tw, P, tidv, nullptr);
-            return;
-        }
         B::template stages<K, 0, false, NORM, TWC>(r, pdep<CM>(tidv), qpre, SUB ? 1u : 0u, tw, P, tidv, nullptr);
     }
     // exchange between pass K and pass K + 1
     template <int K, bool PRE_PRIV> static __device__ __forceinline__ void exch(T (&r)[E], T *lds, uint32_t tidv) {
         constexpr uint32_t RA = S::RMASK[K], RB = S::RMASK[K + 1];
         xsync<PRE_PRIV>();  // what the buffer held has been read
-        if constexpr (!(CNTT_BLK_LAB & 8)) B::template scatter<RA>(r, lds, pdep<FULL & ~RA>(tidv), true);
+        B::template scatter<RA>(r, lds, pdep<FULL & ~RA>(tidv), true);
         xsync<K != HARD>();
-        if constexpr (!(CNTT_BLK_LAB & 8)) B::template gather<RB>(r, (const T *)lds, pdep<FULL & ~RB>(tidv), true);
+        B::template gather<RB>(r, (const T *)lds, pdep<FULL & ~RB>(tidv), true);
     }
 
     // NORM: the last inverse stage also applies 1/N (fused products).
@@ -148,19 +124,13 @@ struct NttBlk {
                                                      const ModParams<T> &P, const HOOK &hook = HOOK{}, uint32_t qpre = 0u) {
         if constexpr (!INV) {
             hook();
-            CNTT_BLK_STAMP(8);
             stages<0, false>(r, tidv, tw, P, qpre);
-            CNTT_BLK_STAMP(1);
             exch<0, false>(r, lds, tidv);  // behind everybody's last read of the previous polynomial; then the one barrier
-            CNTT_BLK_STAMP(2);
             stages<1, false>(r, tidv, tw, P, qpre);
-            CNTT_BLK_STAMP(3);
             exch<1, true>(r, lds, tidv);
             stages<2, false>(r, tidv, tw, P, qpre);
-            CNTT_BLK_STAMP(4);
             exch<2, true>(r, lds, tidv);
             stages<3, false>(r, tidv, tw, P, qpre);
-            CNTT_BLK_STAMP(5);
         } else {
             stages<0, false>(r, tidv, tw, P, qpre);
             exch<0, true>(r, lds, tidv);
@@ -187,16 +157,13 @@ struct NttBlk {
         // hipcc's vmcnt model with loads "in flight" at the loop header: it then waits for them INSIDE the loop, with
         // counts that on every later iteration drain the prefetch of the next polynomial right after it was issued
         // (no overlap of HBM and butterflies at all: measured 102 instead of 80 ns per polynomial at N = 16384).
-        if constexpr (!(CNTT_BLK_LAB & (4 | 16))) {
-            if (tile < nsub) {
-                typename PF::V v0[PF::NVEC];
-                PF::issue(v0, (const T *)(data + ((size_t)tile << LOGN)), pdep<CML>(tid) * (uint32_t)sizeof(T));
-                PF::template wait<0>(v0);
-                PF::unpack(r, v0);
-            }
+        if (tile < nsub) {
+            typename PF::V v0[PF::NVEC];
+            PF::issue(v0, (const T *)(data + ((size_t)tile << LOGN)), pdep<CML>(tid) * (uint32_t)sizeof(T));
+            PF::template wait<0>(v0);
+            PF::unpack(r, v0);
         }
         for (; tile < nsub; tile += gridDim.x) {
-            CNTT_BLK_STAMP(0);
             // every address of the body is recomputed from an opaque copy of the thread index: left alone hipcc hoists
             // them all out of the loop and spills (128 VGPRs: sixteen wavefronts per CU)
             uint32_t tidv = tid;
@@ -205,14 +172,8 @@ struct NttBlk {
             const bool more = tnext < nsub;  // workgroup-uniform
             T *tbase = data + ((size_t)tile << LOGN);
             typename PF::V vn[PF::NVEC];
-            if constexpr (CNTT_BLK_LAB & 16) {
-            } else if constexpr (CNTT_BLK_LAB & 4) {
-                B::template gather_tile<LOAD_RM>(r, (const T *)(data + ((size_t)tile << LOGN)), pdep<CML>(tidv) * (uint32_t)sizeof(T));
-            }
             auto prefetch = [&]() {
-                if constexpr (!(CNTT_BLK_LAB & (4 | 16))) {
-                    if (more) PF::issue(vn, (const T *)(data + ((size_t)((CNTT_BLK_LAB & 64) ? (tnext & 255u) : tnext) << LOGN)), pdep<CML>(tidv) * (uint32_t)sizeof(T));
-                }
+                if (more) PF::issue(vn, (const T *)(data + ((size_t)tnext << LOGN)), pdep<CML>(tidv) * (uint32_t)sizeof(T));
             };
 #pragma unroll
             for (int j = 0; j < E; ++j) r[j] = Bfly<T, CLS>::load_fix(r[j], P);
@@ -222,49 +183,26 @@ struct NttBlk {
                 for (int j = 0; j < E; ++j) r[j] = Bfly<T, CLS>::finish_fwd(r[j], P);
                 if constexpr (STORE_RM != RM3) {
                     xsync<true>();  // block transpose into the coalesced layout (wave-private)
-                    if constexpr (!(CNTT_BLK_LAB & 8)) B::template scatter<RM3>(r, lds, pdep<FULL & ~RM3>(tidv), true);
+                    B::template scatter<RM3>(r, lds, pdep<FULL & ~RM3>(tidv), true);
                     xsync<true>();
-                    if constexpr (!(CNTT_BLK_LAB & 8)) B::template gather<BLK_IO>(r, (const T *)lds, pdep<CMS>(tidv), true);
+                    B::template gather<BLK_IO>(r, (const T *)lds, pdep<CMS>(tidv), true);
                 }
             } else {
                 xsync<false>();  // everybody has read the previous polynomial's transpose
                 if constexpr (LOAD_RM != RM0) {
-                    if constexpr (!(CNTT_BLK_LAB & 8)) B::template scatter<BLK_IO>(r, lds, pdep<CML>(tidv), true);
+                    B::template scatter<BLK_IO>(r, lds, pdep<CML>(tidv), true);
                     xsync<true>();
-                    if constexpr (!(CNTT_BLK_LAB & 8)) B::template gather<RM0>(r, (const T *)lds, pdep<FULL & ~RM0>(tidv), true);
+                    B::template gather<RM0>(r, (const T *)lds, pdep<FULL & ~RM0>(tidv), true);
                 }
                 transform<false>(r, lds, tidv, tw, P, prefetch);
 #pragma unroll
                 for (int j = 0; j < E; ++j) r[j] = Bfly<T, CLS>::finish_inv(r[j], P);
             }
-            if constexpr (CNTT_BLK_LAB & (16 | 32)) {
-                if (r[0] == 0x123456789ull) tbase[tid] = r[1] ^ r[2] ^ r[3] ^ r[4] ^ r[5] ^ r[6] ^ r[7] ^ r[8] ^ r[9] ^ r[10] ^ r[11] ^ r[12] ^ r[13] ^ r[14] ^ r[15];
-            } else
-            CNTT_BLK_STAMP(9);
-#ifdef CNTT_BLK_NT
-            {
-                constexpr int NVS = nv<STORE_RM>();
-                using VS = typename VecOf<T, NVS>::type;
-                const uint32_t so = pdep<CMS>(tidv) * (uint32_t)sizeof(T);
-#pragma unroll
-                for (int j = 0; j < E; j += NVS) {
-                    VS v;
-                    if constexpr (NVS == 1) v = r[j];
-                    else { v[0] = r[j]; v[1] = r[j + 1]; }
-                    __builtin_nontemporal_store(v, reinterpret_cast<VS *>(reinterpret_cast<char *>(tbase) + so + cdep((uint32_t)j, STORE_RM) * (uint32_t)sizeof(T)));
-                }
+            B::template scatter_tile<STORE_RM>(r, tbase, pdep<CMS>(tidv) * (uint32_t)sizeof(T));
+            if (more) {
+                PF::template wait<NST>(vn);
+                PF::unpack(r, vn);
             }
-#else
-                B::template scatter_tile<STORE_RM>(r, tbase, pdep<CMS>(tidv) * (uint32_t)sizeof(T));
-#endif
-            CNTT_BLK_STAMP(6);
-            if constexpr (!(CNTT_BLK_LAB & (4 | 16))) {
-                if (more) {
-                    PF::template wait<NST>(vn);
-                    PF::unpack(r, vn);
-                }
-            }
-            CNTT_BLK_STAMP(7);
         }
     }
 };
@@ -640,7 +578,8 @@ struct ExtBlk {
 
     static __device__ __forceinline__ void run(T *__restrict__ out, const T *__restrict__ terms, const T *__restrict__ key_ntt,
                                                const TwPair<T> *__restrict__ twf, const TwPair<T> *__restrict__ twi,
-                                               const ModParams<T> &P, uint32_t nb, uint32_t nterms, bool accumulate, T *lds) {
+                                               const ModParams<T> &P, uint32_t nb, uint32_t nterms, bool accumulate, uint32_t ostride,
+                                               T *lds) {
         constexpr uint32_t CMIO = FULL & ~RMIO, CMM = FULL & ~RMM;
         const uint32_t tid = threadIdx.x;
         for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
@@ -671,7 +610,7 @@ struct ExtBlk {
                     for (int e = 0; e < E; ++e) r[e] = Bfly<T, CLS>::reduce(r[e], P);
                 }
                 static_for<0, NOUT>([&](auto o) {
-                    mul_acc_key(acc[o.value], r, key_ntt + (((size_t)j * NOUT + o.value) << LOGN), pdep<CMM>(tj), P);
+                    mul_acc_key(acc[o.value], r, key_ntt + (((size_t)j * ostride + o.value) << LOGN), pdep<CMM>(tj), P);
                     if constexpr (Bfly<T, CLS>::IS_FP) {  // every product adds at most 0.875 p to the lazy accumulator
                         if ((j + 1u) % (uint32_t)Bfly<T, CLS>::ACC_REDUCE_EVERY == 0u) {
 #pragma unroll
@@ -690,7 +629,7 @@ struct ExtBlk {
                 I::template transform<false>(a, lds, tidv, twi, P);
 #pragma unroll
                 for (int e = 0; e < E; ++e) a[e] = Bfly<T, CLS>::finish_inv(a[e], P);
-                T *dst = out + (((size_t)b * NOUT + o.value) << LOGN);
+                T *dst = out + (((size_t)b * ostride + o.value) << LOGN);
                 if (accumulate) {
                     T old[E];
                     FB::template gather_tile<RMIO>(old, (const T *)dst, pdep<CMIO>(tidv) * (uint32_t)sizeof(T));
@@ -708,10 +647,11 @@ __global__ __launch_bounds__((ExtBlk<T, LOGN, CLS, NOUT>::WPB), WPW) void ext_ke
                                                                                    const T *__restrict__ key_ntt,
                                                                                    const TwPair<T> *__restrict__ twf,
                                                                                    const TwPair<T> *__restrict__ twi, const ModParams<T> P,
-                                                                                   uint32_t nb, uint32_t nterms, uint32_t accumulate) {
+                                                                                   uint32_t nb, uint32_t nterms, uint32_t accumulate,
+                                                                                   uint32_t ostride) {
     using K = ExtBlk<T, LOGN, CLS, NOUT>;
     __shared__ __attribute__((aligned(16))) T lds[K::FB::LDS_WORDS_1];
-    K::run(out, terms, key_ntt, twf, twi, P, nb, nterms, accumulate != 0, lds);
+    K::run(out, terms, key_ntt, twf, twi, P, nb, nterms, accumulate != 0, ostride, lds);
 }
 
 }  // namespace cntt

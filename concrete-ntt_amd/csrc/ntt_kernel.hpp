@@ -572,6 +572,10 @@ struct NttKernel {
     }
 };
 
+// FAM: schedule family (gen_sched.py).  32-bit words from N = 8192 up run family 3 (padded exchange layout: one LDS base per pass +
+// immediate offsets instead of a shift / xor / or per access -- a sixth of the instructions of these VALU-bound kernels).
+template <class T, int LOGN, bool SUB> constexpr int plain_fam() { return (sizeof(T) == 4 && LOGN >= 13 && !SUB) ? 3 : 0; }
+
 // -------------------------------------------------------------------------------------------------
 // Persistent, software-pipelined variant for polynomials that live in one wavefront (N <= 1024).
 // Each workgroup stages the thread-dependent twiddles once in LDS (fill_image) and then walks tiles of
@@ -601,58 +605,6 @@ struct NttWp : NttKernel<T, LOGN, INV, CLS, false, FAM> {
         }
     }
 
-#ifdef CNTT_LAB_XLANE
-    // Four (register bit <-> lane bit) transpositions of 16 64-bit coefficients, the shape of the N = 1024 transform's last
-    // exchange (lane bits 5, 4 or 2, 1, 0): v_permlane32_swap / v_permlane16_swap move a register pair's halves in one
-    // instruction per 32-bit word (16 each); the lane bits inside a row of 16 need a DPP move plus a select per word and
-    // direction (2 x 16 each for quad_perm bits 0 and 1).  Lab only.
-    static __device__ __forceinline__ void xlane_exchange(T (&r)[E]) {
-        uint32_t w[2 * E];
-#pragma unroll
-        for (int j = 0; j < E; ++j) {
-            w[2 * j] = (uint32_t)r[j];
-            w[2 * j + 1] = (uint32_t)(r[j] >> 32);
-        }
-        const bool b0 = threadIdx.x & 1, b1 = threadIdx.x & 2;
-#pragma unroll
-        for (int j = 0; j < E; j += 2) {   // register bit 0 <-> lane bit 5, then register bit 1 <-> lane bit 4
-#pragma unroll
-            for (int h = 0; h < 2; ++h) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(w[2 * j + h]), "+v"(w[2 * (j + 1) + h]));
-        }
-#pragma unroll
-        for (int j = 0; j < E; ++j) {
-            if (j & 2) continue;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(w[2 * j + h]), "+v"(w[2 * (j + 2) + h]));
-        }
-#pragma unroll
-        for (int j = 0; j < E; ++j) {      // register bit 2 <-> lane bit 0 (quad_perm [1,0,3,2]), register bit 3 <-> lane bit 1 ([2,3,0,1])
-            if (j & 4) continue;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const uint32_t a = w[2 * j + h], c = w[2 * (j + 4) + h];
-                const uint32_t ta = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c, 0xb1, 0xf, 0xf, false);
-                const uint32_t tc = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, 0xb1, 0xf, 0xf, false);
-                w[2 * j + h] = b0 ? ta : a;
-                w[2 * (j + 4) + h] = b0 ? c : tc;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < E; ++j) {
-            if (j & 8) continue;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const uint32_t a = w[2 * j + h], c = w[2 * (j + 8) + h];
-                const uint32_t ta = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c, 0x4e, 0xf, 0xf, false);
-                const uint32_t tc = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, 0x4e, 0xf, 0xf, false);
-                w[2 * j + h] = b1 ? ta : a;
-                w[2 * (j + 8) + h] = b1 ? c : tc;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < E; ++j) r[j] = (T)w[2 * j] | ((T)w[2 * j + 1] << 32);
-    }
-#endif
 
     // IMG: thread-dependent twiddles come from the workgroup's LDS image (fill_image); otherwise from the table in
     // global memory (L2), for kernels that walk several primes and cannot hold an image per prime
@@ -663,20 +615,8 @@ struct NttWp : NttKernel<T, LOGN, INV, CLS, false, FAM> {
                                                 const TwPair<T> *img, const ModParams<T> &P) {
         constexpr uint32_t RM = S::RMASK[K], CM = FULL & ~RM;
         const uint32_t ebase = pdep<CM>(tid);
-#ifdef CNTT_LAB_XLANE
-        // tools/ntt_lab.hip, TIMING ONLY (wrong results): the LAST exchange of a wave-private transform as cross-lane
-        // register traffic with the instruction mix of a correct implementation (see xlane_exchange) instead of LDS
-        constexpr bool XL = B::WAVE_PRIVATE && sizeof(T) == 8 && NPASS >= 2;
-        if constexpr (K > 0 && !(XL && K == NPASS - 1)) B::template gather<RM>(r, (const T *)lds, ebase, true);
-        B::template stages<K, 0, IMG, NORM, TWC>(r, ebase, 0u, 0u, tw, P, tid, img);
-        if constexpr (XL && K == NPASS - 2) {
-            xlane_exchange(r);
-            pass<K + 1, NORM, IMG, FIN, TWC>(r, lds, tid, tw, img, P);
-        } else
-#else
         if constexpr (K > 0) B::template gather<RM>(r, (const T *)lds, ebase, true);
         B::template stages<K, 0, IMG, NORM, TWC>(r, ebase, 0u, 0u, tw, P, tid, img);
-#endif
         if constexpr (K < NPASS - 1) {
             if constexpr (K > 0) wsync();
             B::template scatter<RM>(r, lds, ebase, true);
@@ -906,8 +846,9 @@ __global__ __launch_bounds__(WPB, WPW) void mul_kernel_wp(T *__restrict__ lhs, c
 template <class T, int LOGN, int CLS>
 struct MulOne {
     static constexpr int TPP = NttKernel<T, LOGN, false, CLS, false>::TPP;
-    using F = NttWp<T, LOGN, false, CLS, TPP>;
-    using I = NttWp<T, LOGN, true, CLS, TPP>;
+    static constexpr int FAM = plain_fam<T, LOGN, false>();
+    using F = NttWp<T, LOGN, false, CLS, TPP, FAM>;
+    using I = NttWp<T, LOGN, true, CLS, TPP, FAM>;
     using FB = typename F::B;
     using IB = typename I::B;
     static constexpr int E = FB::E, NPASS = FB::NPASS;
@@ -954,6 +895,8 @@ __global__ __launch_bounds__((MulOne<T, LOGN, CLS>::TPP)) void mul_kernel_one(T 
 // -------------------------------------------------------------------------------------------------
 // Fused mul_accumulate chain (the step around the NTT in the reference's caller):
 //     for each o < NOUT:  out[b][o] (+)= inv( sum_{j < J} fwd(terms[b][j]) (.) key_ntt[j][o] )
+// (`ostride` >= NOUT: outputs per batch element in `out` / per term in `key_ntt` -- a caller that splits the outputs of one chain over
+// two launches passes base pointers offset to its first output and the full count as stride)
 // i.e. what a caller of the reference writes as
 //     for j { plan.fwd(t_j); for o { plan.mul_accumulate(acc_o, t_j, key[j][o]) } }  for o { plan.inv(acc_o) }
 // (src/prime64.rs:794, :1085-1128, :872) with every intermediate kept in registers: (J + NOUT) * N words of HBM
@@ -1005,7 +948,7 @@ struct ExtWp {
     static __device__ __forceinline__ void run(T *__restrict__ out, const T *__restrict__ terms,
                                                const T *__restrict__ key_ntt, const TwPair<T> *__restrict__ twf,
                                                const TwPair<T> *__restrict__ twi, const ModParams<T> &P, uint32_t nb,
-                                               uint32_t nterms, bool accumulate, T *lds_all, TwPair<T> *imgf,
+                                               uint32_t nterms, bool accumulate, uint32_t ostride, T *lds_all, TwPair<T> *imgf,
                                                TwPair<T> *imgi) {
         FB::fill_image(imgf, twf);
         IB::fill_image(imgi, twi);
@@ -1062,7 +1005,7 @@ struct ExtWp {
                 }
                 const uint32_t ebM = !OPAQUE ? ebaseM : pdep<CMM>(tj);
                 static_for<0, NOUT>([&](auto o) {
-                    mul_acc_key(acc[o.value], r, key_ntt + (((size_t)j * NOUT + o.value) << LOGN), ebM, P);
+                    mul_acc_key(acc[o.value], r, key_ntt + (((size_t)j * ostride + o.value) << LOGN), ebM, P);
                     if constexpr (Bfly<T, CLS>::IS_FP) {  // every product adds at most 0.875 p to the lazy accumulator
                         if ((j + 1u) % (uint32_t)Bfly<T, CLS>::ACC_REDUCE_EVERY == 0u) {
 #pragma unroll
@@ -1090,7 +1033,7 @@ struct ExtWp {
                     F::wsync();
                     FB::template gather<IO_RM>(a, (const T *)lds, ebIO, true);
                 }
-                T *dst = out + (((size_t)bc * NOUT + o.value) << LOGN);
+                T *dst = out + (((size_t)bc * ostride + o.value) << LOGN);
                 if (accumulate) {
                     T old[E];
                     FB::template gather<IO_RM>(old, (const T *)dst, ebIO, false);
@@ -1110,7 +1053,7 @@ struct ExtWp {
 template <class T, int LOGN, int CLS, int NOUT>
 struct ExtOne {
     static constexpr int TPP = NttKernel<T, LOGN, false, CLS, false>::TPP;
-    using X = ExtWp<T, LOGN, CLS, TPP, NOUT>;
+    using X = ExtWp<T, LOGN, CLS, TPP, NOUT, plain_fam<T, LOGN, false>()>;
     using F = typename X::F;
     using I = typename X::I;
     using FB = typename X::FB;
@@ -1119,7 +1062,7 @@ struct ExtOne {
 
     static __device__ __forceinline__ void run(T *__restrict__ out, const T *__restrict__ terms, const T *__restrict__ key_ntt,
                                                const TwPair<T> *__restrict__ twf, const TwPair<T> *__restrict__ twi,
-                                               const ModParams<T> &P, uint32_t nterms, bool accumulate, T *lds) {
+                                               const ModParams<T> &P, uint32_t nterms, bool accumulate, uint32_t ostride, T *lds) {
         constexpr uint32_t CM0 = FULL & ~RM0, CMM = FULL & ~RMM, CML = FULL & ~RML;
         const uint32_t tid = threadIdx.x, b = blockIdx.x;
         const T *tb = terms + (((size_t)b * nterms) << LOGN);
@@ -1142,7 +1085,7 @@ struct ExtOne {
             }
             const uint32_t ebM = pdep<CMM>(tj);
             static_for<0, NOUT>([&](auto o) {
-                X::mul_acc_key(acc[o.value], r, key_ntt + (((size_t)j * NOUT + o.value) << LOGN), ebM, P);
+                X::mul_acc_key(acc[o.value], r, key_ntt + (((size_t)j * ostride + o.value) << LOGN), ebM, P);
                 if constexpr (Bfly<T, CLS>::IS_FP) {
                     if ((j + 1u) % (uint32_t)Bfly<T, CLS>::ACC_REDUCE_EVERY == 0u) {
 #pragma unroll
@@ -1159,7 +1102,7 @@ struct ExtOne {
 #pragma unroll
             for (int e = 0; e < E; ++e) a[e] = Bfly<T, CLS>::pre_inverse(a[e], P);
             I::template pass<0, false, false>(a, lds, to, twi, nullptr, P);  // canonical coefficients, layout RML
-            T *dst = out + (((size_t)b * NOUT + o.value) << LOGN);
+            T *dst = out + (((size_t)b * ostride + o.value) << LOGN);
             if (accumulate) {
                 T old[E];
                 FB::template gather<RML>(old, (const T *)dst, pdep<CML>(to), false);
@@ -1178,28 +1121,28 @@ __global__ __launch_bounds__((ExtOne<T, LOGN, CLS, NOUT>::TPP)) void ext_kernel_
                                                                                  const TwPair<T> *__restrict__ twf,
                                                                                  const TwPair<T> *__restrict__ twi,
                                                                                  const ModParams<T> P, uint32_t nterms,
-                                                                                 uint32_t accumulate) {
+                                                                                 uint32_t accumulate, uint32_t ostride) {
     using K = ExtOne<T, LOGN, CLS, NOUT>;
     __shared__ __attribute__((aligned(16))) T lds[K::FB::LDS_WORDS_1];
-    K::run(out, terms, key_ntt, twf, twi, P, nterms, accumulate != 0, lds);
+    K::run(out, terms, key_ntt, twf, twi, P, nterms, accumulate != 0, ostride, lds);
 }
 
 template <class T, int LOGN, int CLS, int WPB, int WPW, int NOUT, int FAM = 0>
 __global__ __launch_bounds__(WPB, WPW) void ext_kernel_wp(T *__restrict__ out, const T *__restrict__ terms,
                                                       const T *__restrict__ key_ntt, const TwPair<T> *__restrict__ twf,
                                                       const TwPair<T> *__restrict__ twi, const ModParams<T> P,
-                                                      uint32_t nb, uint32_t nterms, uint32_t accumulate) {
+                                                      uint32_t nb, uint32_t nterms, uint32_t accumulate, uint32_t ostride) {
     using K = ExtWp<T, LOGN, CLS, WPB, NOUT, FAM>;
     __shared__ __attribute__((aligned(16))) T lds[(size_t)K::PPB * K::FB::LDS_WORDS_1];
     __shared__ __attribute__((aligned(16))) TwPair<T> imgf[K::FB::IMG_ENTRIES];
     __shared__ __attribute__((aligned(16))) TwPair<T> imgi[K::IB::IMG_ENTRIES];
-    K::run(out, terms, key_ntt, twf, twi, P, nb, nterms, accumulate != 0, lds, imgf, imgi);
+    K::run(out, terms, key_ntt, twf, twi, P, nb, nterms, accumulate != 0, ostride, lds, imgf, imgi);
 }
 
-template <class T, int LOGN, bool INV, int CLS, bool SUB>
-__global__ __launch_bounds__((NttKernel<T, LOGN, INV, CLS, SUB>::BLOCK)) void ntt_kernel(
+template <class T, int LOGN, bool INV, int CLS, bool SUB, int FAM = 0>
+__global__ __launch_bounds__((NttKernel<T, LOGN, INV, CLS, SUB, FAM>::BLOCK)) void ntt_kernel(
     T *__restrict__ data, const TwPair<T> *__restrict__ tw, const ModParams<T> P, uint32_t nsub, uint32_t depth) {
-    using K = NttKernel<T, LOGN, INV, CLS, SUB>;
+    using K = NttKernel<T, LOGN, INV, CLS, SUB, FAM>;
     __shared__ __attribute__((aligned(16))) T lds[K::LDS_ELEMS];
     K::run(data, tw, P, nsub, depth, lds);
 }

@@ -13,7 +13,7 @@ template <class T> struct MaxLdsLogN;
 template <> struct MaxLdsLogN<uint64_t> { static constexpr int value = 14; };
 template <> struct MaxLdsLogN<uint32_t> { static constexpr int value = 15; };
 // largest size whose transforms run in CLS_FPW: the 32768-point kernel (one 1024-thread workgroup, 128 VGPRs) would spill
-constexpr int MAX_FPW_LOGN = 14;
+constexpr int MAX_FPW_LOGN = 15;
 template <class T> struct MinLogN;
 template <> struct MinLogN<uint64_t> { static constexpr int value = 4; };  // src/prime64.rs:709
 template <> struct MinLogN<uint32_t> { static constexpr int value = 5; };  // src/prime32.rs:635
@@ -47,19 +47,32 @@ hipError_t launch_mul_ntt(int logn, int cls, T *lhs, const T *rhs_ntt, const TwP
 template <class T, int NOUT>
 hipError_t launch_ext_ntt_n(int logn, int cls, T *out, const T *terms, const T *key_ntt, const TwPair<T> *twf,
                             const TwPair<T> *twi, const ModParams<T> &P, uint32_t batch, uint32_t nterms, bool accumulate,
-                            hipStream_t stream);
+                            hipStream_t stream, uint32_t ostride);
+bool ext_split_enabled();   // CNTT_EXT_SPLIT=0: no split launches (A/B timing: the composed path instead)
 template <class T>
 inline hipError_t launch_ext_ntt(int logn, int cls, T *out, const T *terms, const T *key_ntt, const TwPair<T> *twf,
                                  const TwPair<T> *twi, const ModParams<T> &P, uint32_t batch, uint32_t nterms, uint32_t nout,
                                  bool accumulate, hipStream_t stream) {
+    hipError_t e = hipErrorNotSupported;
     switch (nout) {
     case 0: return hipSuccess;
-    case 1: return launch_ext_ntt_n<T, 1>(logn, cls, out, terms, key_ntt, twf, twi, P, batch, nterms, accumulate, stream);
-    case 2: return launch_ext_ntt_n<T, 2>(logn, cls, out, terms, key_ntt, twf, twi, P, batch, nterms, accumulate, stream);
-    case 3: return launch_ext_ntt_n<T, 3>(logn, cls, out, terms, key_ntt, twf, twi, P, batch, nterms, accumulate, stream);
-    case 4: return launch_ext_ntt_n<T, 4>(logn, cls, out, terms, key_ntt, twf, twi, P, batch, nterms, accumulate, stream);
+    case 1: e = launch_ext_ntt_n<T, 1>(logn, cls, out, terms, key_ntt, twf, twi, P, batch, nterms, accumulate, stream, 1); break;
+    case 2: e = launch_ext_ntt_n<T, 2>(logn, cls, out, terms, key_ntt, twf, twi, P, batch, nterms, accumulate, stream, 2); break;
+    case 3: e = launch_ext_ntt_n<T, 3>(logn, cls, out, terms, key_ntt, twf, twi, P, batch, nterms, accumulate, stream, 3); break;
+    case 4: e = launch_ext_ntt_n<T, 4>(logn, cls, out, terms, key_ntt, twf, twi, P, batch, nterms, accumulate, stream, 4); break;
     default: return hipErrorNotSupported;
     }
+    if (e != hipErrorNotSupported || nout < 3 || !ext_split_enabled()) return e;
+    // Three / four outputs where only the one- / two-output kernels exist (64-bit words at n = 16384, 32-bit words at n = 32768:
+    // the accumulator tiles do not fit 128 VGPRs): TWO fused launches of <= 2 outputs.  The terms are transformed twice, but
+    // nothing else touches HBM; the composed path moves (2J + 3JO + 2O) n words in five launches.
+    (void)hipGetLastError();
+    e = launch_ext_ntt_n<T, 2>(logn, cls, out, terms, key_ntt, twf, twi, P, batch, nterms, accumulate, stream, nout);
+    if (e != hipSuccess) return e;
+    T *out2 = out + ((size_t)2 << logn);
+    const T *key2 = key_ntt + ((size_t)2 << logn);
+    if (nout == 3) return launch_ext_ntt_n<T, 1>(logn, cls, out2, terms, key2, twf, twi, P, batch, nterms, accumulate, stream, nout);
+    return launch_ext_ntt_n<T, 2>(logn, cls, out2, terms, key2, twf, twi, P, batch, nterms, accumulate, stream, nout);
 }
 
 // Whole negacyclic_polymul of one native Plan32 kind (native_fused.hpp) for 32 <= n <= 16384; hipErrorNotSupported
@@ -83,8 +96,10 @@ hipError_t launch_native_fused(int logn, void *prod, const void *lhs, const void
                                const CrtArgs &C, uint32_t batch, uint32_t *scratch, hipStream_t st, const AccArgs *acc,
                                const void *tables_acc);
 // sizes / kinds of native_polymul_kernel_acc (no workspace, no parking)
+// (words of at most 64 bits up to n = 16384 -- 16 coefficients per thread, three words of state each; the 16-byte words of
+// native128 / native_binary128 -- five words of state -- up to n = 4096, where a product is at most 256 threads at 168 VGPRs)
 constexpr bool native_fused_acc(int kind, int logn) {
-    return (kind == 0 || kind == 1 || kind == 3 || kind == 4) && logn >= 5 && logn <= 12;
+    return (kind == 2 || kind == 5) ? (logn >= 5 && logn <= 12) : (kind >= 0 && kind <= 4 && logn >= 5 && logn <= 14);
 }
 bool native_acc_enabled();
 inline int device_num_cus() {

@@ -80,8 +80,8 @@ static hipError_t launch_one(T *data, const TwPair<T> *tw, const ModParams<T> &P
                            tw, P, nsub);
     } else {
         const uint32_t grid = (nsub + K::PPB - 1) / K::PPB;
-        hipLaunchKernelGGL((ntt_kernel<T, LOGN, INV, CLS, SUB>), dim3(grid), dim3(K::BLOCK), 0, stream, data, tw, P,
-                           nsub, depth);
+        hipLaunchKernelGGL((ntt_kernel<T, LOGN, INV, CLS, SUB, plain_fam<T, LOGN, SUB>()>), dim3(grid), dim3(K::BLOCK), 0, stream, data,
+                           tw, P, nsub, depth);
     }
     return hipGetLastError();
 }

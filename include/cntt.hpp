@@ -8,6 +8,9 @@
 // Where the reference returns None this returns std::nullopt; where it panics (length asserts, modulus <= 1) this
 // throws cntt::Panic; HIP failures -- including "no GPU": there is no CPU path -- throw cntt::DeviceError.
 // The *_batch methods are the device-resident batched extension (see cntt.h for layouts).
+// INPUT CONTRACT (cntt.h): coefficients handed to fwd / inv / the pointwise calls are canonical, 0 <= x < modulus.  Words >= modulus are
+// neither rejected nor reduced: the call completes, the affected outputs are unspecified residues (as in the reference, whose back ends
+// disagree with each other outside that range).
 #pragma once
 #include <cstddef>
 #include <cstdint>

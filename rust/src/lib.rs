@@ -85,7 +85,11 @@ macro_rules! prime_plan {
                 let rc = unsafe { ffi::$new(polynomial_size, modulus, &mut out) };
                 option_of(rc, out).map(|raw| Self { raw, owned: true })
             }
-            pub(crate) fn borrowed(raw: *const ffi::$handle) -> Self { Self { raw: raw as *mut _, owned: false } }
+            /// A plan that lives inside a native / product plan: handed out only as a `PlanRef<'parent>` (never dropped, never
+            /// outliving the parent: the C++ object belongs to the parent handle and is freed with it).
+            pub(crate) unsafe fn borrowed<'a>(raw: *const ffi::$handle) -> PlanRef<'a> {
+                PlanRef { plan: core::mem::ManuallyDrop::new(Self { raw: raw as *mut _, owned: false }), _parent: core::marker::PhantomData }
+            }
             pub fn ntt_size(&self) -> usize { unsafe { ffi::$size(self.raw) } }
             pub fn modulus(&self) -> $word { unsafe { ffi::$modulus(self.raw) } }
             /// p_barrett, big_q, n_inv_mod_p, root ... (private fields of the reference)
@@ -103,6 +107,8 @@ macro_rules! prime_plan {
                 }
             }
             /// In-place forward transform, standard order in, bit-reversed order out; panics unless `buf.len() == ntt_size()`.
+            /// Input contract (as the reference's tests feed it, include/cntt.h): every coefficient `< modulus`.  Larger words are not
+            /// rejected and not reduced: the call completes and the outputs they reach are unspecified residues.
             #[track_caller]
             pub fn fwd(&self, buf: &mut [$word]) { check(unsafe { ffi::$fwd(self.raw, buf.as_mut_ptr(), buf.len()) }) }
             /// In-place inverse transform (unnormalised: `inv(fwd(x)) = n x`).
@@ -198,6 +204,20 @@ macro_rules! prime_plan {
         impl Drop for Plan {
             fn drop(&mut self) { if self.owned { unsafe { ffi::$free(self.raw) } } }
         }
+        /// What `ntt_0()` ... of the native plans and `plan_32()` / `plan_64()` of the product plan return where the reference returns
+        /// `&Plan`: a borrow-carrying handle that derefs to `Plan` (every `&self` method; `.clone()` gives an owned, independent
+        /// plan).  The lifetime is the borrow of the parent plan, so safe code cannot use it after the parent is dropped.
+        pub struct PlanRef<'a> {
+            plan: core::mem::ManuallyDrop<Plan>,
+            _parent: core::marker::PhantomData<&'a ()>,
+        }
+        impl<'a> core::ops::Deref for PlanRef<'a> {
+            type Target = Plan;
+            fn deref(&self) -> &Plan { &self.plan }
+        }
+        impl<'a> core::fmt::Debug for PlanRef<'a> {
+            fn fmt(&self, f: &mut core::fmt::Formatter<'_>) -> core::fmt::Result { core::fmt::Debug::fmt(&**self, f) }
+        }
         /// Like the reference (src/prime64.rs:238-245): only `ntt_size` and `modulus`.
         impl core::fmt::Debug for Plan {
             fn fmt(&self, f: &mut core::fmt::Formatter<'_>) -> core::fmt::Result {
@@ -275,8 +295,8 @@ macro_rules! native_plan {
             pub fn try_new(n: usize) -> Option<Self> { NativeRaw::try_new($kind, n).map(Self) }
             pub fn ntt_size(&self) -> usize { self.0.ntt_size() }
             $(
-                /// Borrowed prime plan of residue `$i` (the reference returns `&Plan`; this handle is not freed on drop).
-                pub fn $acc(&self) -> $sub::Plan { $sub::Plan::borrowed(unsafe { ffi::$getter((self.0).0, $i) }) }
+                /// Borrowed prime plan of residue `$i` (the reference returns `&Plan`): tied to `&self`, derefs to `Plan`.
+                pub fn $acc(&self) -> $sub::PlanRef<'_> { unsafe { $sub::Plan::borrowed(ffi::$getter((self.0).0, $i)) } }
             )*
             /// `residues[i] <- NTT_i(value mod P_i)`; panics unless every slice has `ntt_size()` elements.
             #[track_caller]
@@ -463,11 +483,11 @@ pub mod product {
             let k = unsafe { ffi::cntt_product_nprimes32(self.0) + ffi::cntt_product_nprimes64(self.0) };
             (0..k).map(|i| unsafe { ffi::cntt_product_prime(self.0, i) }).collect()
         }
-        pub fn plan_32(&self) -> Vec<prime32::Plan> {
-            (0..unsafe { ffi::cntt_product_nprimes32(self.0) }).map(|i| prime32::Plan::borrowed(unsafe { ffi::cntt_product_ntt32(self.0, i) })).collect()
+        pub fn plan_32(&self) -> Vec<prime32::PlanRef<'_>> {
+            (0..unsafe { ffi::cntt_product_nprimes32(self.0) }).map(|i| unsafe { prime32::Plan::borrowed(ffi::cntt_product_ntt32(self.0, i)) }).collect()
         }
-        pub fn plan_64(&self) -> Vec<prime64::Plan> {
-            (0..unsafe { ffi::cntt_product_nprimes64(self.0) }).map(|i| prime64::Plan::borrowed(unsafe { ffi::cntt_product_ntt64(self.0, i) })).collect()
+        pub fn plan_64(&self) -> Vec<prime64::PlanRef<'_>> {
+            (0..unsafe { ffi::cntt_product_nprimes64(self.0) }).map(|i| unsafe { prime64::Plan::borrowed(ffi::cntt_product_ntt64(self.0, i)) }).collect()
         }
         pub fn modular_inverses(&self) -> Vec<u64> {
             let k = self.primes().len();

@@ -95,7 +95,11 @@ def check_kernel(name, insts):
 def persistent_kernels(tmp_path):
     """(name, [(address, text)]) of every persistent software-pipelined kernel in the built objects.  The objects are
     part of the build (__graft_entry__.build() runs before the tests): their absence is a failure, not a skip."""
-    assert os.path.exists(os.path.join(LLVM, "llvm-objdump")), "ROCm LLVM tools not present"
+    if not os.path.exists(os.path.join(LLVM, "llvm-objdump")):
+        # no ROCm toolchain on this machine: nothing can read the code objects (ADVICE round 3).  Where the tools exist (the build
+        # image, the GPU box) missing objects still fail below; CNTT_REQUIRE_CODE_OBJECTS=1 turns this skip into a failure.
+        assert os.environ.get("CNTT_REQUIRE_CODE_OBJECTS") != "1", "ROCm LLVM tools not present"
+        pytest.skip("ROCm LLVM tools not present on this machine")
     for unit in UNITS:
         obj = os.path.join(OBJ, unit + ".o")
         assert os.path.exists(obj), "objects not built in-tree (run __graft_entry__.build())"

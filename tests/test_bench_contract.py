@@ -157,3 +157,32 @@ def test_one_rank_rccl_rehearsal():
     assert "error" not in json.dumps(d["configs"]), d["configs"]
     e2e = by_name["C4 prime64 N=16384 end to end"]
     assert e2e["scatter_s"] > 0 and e2e["compute_s"] > 0 and e2e["gather_s"] > 0
+
+
+@pytest.mark.gpu
+def test_line_carries_clock_and_power_and_the_watchdog_keeps_the_line():
+    """(1) roofline.sclk_mhz / power_w: sampled from the card's hwmon files (or amdsmi) while the timed region ran, so that a slow
+    driver run can be told from a slow build.  (2) A leg after the timed region that does not return must not cost the headline
+    line: the watchdog prints it with what finished, names the running leg, flags the line (`extras_watchdog`) and ends the rank
+    -- with status 0 by default (a launcher must not discard a complete headline), 3 with --extras-strict."""
+    base = [sys.executable, BENCH, "--steps", "50", "--warmup", "2", "--ramp-seconds", "0.5", "--batch", "16384", "--c4-batch",
+            "256", "--no-cpu-baseline"]
+    r = subprocess.run(base, capture_output=True, text=True, cwd=ROOT, env=clean_env(), timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = one_json_line(r.stdout)
+    rf = d["roofline"]
+    assert rf["sensors"]["source"], rf["sensors"]
+    assert 400 <= rf["sclk_mhz"] <= 2500 and 100 <= rf["power_w"] <= 1500, (rf["sclk_mhz"], rf["power_w"])
+    assert rf["sensors"]["fused_kernel"]["samples"] >= 1 and rf["sensors"]["fwd_kernel"]["samples"] >= 1
+    c3 = [c for c in d["configs"] if c["config"].startswith("C3")][0]
+    assert c3["sclk_mhz"] and c3["power_w"]
+    # the watchdog: one second is not enough for the extras
+    assert d["extras_watchdog"] is False
+    for strict, want in ((False, 0), (True, 3)):
+        r = subprocess.run(base + ["--extras-timeout", "1"] + (["--extras-strict"] if strict else []), capture_output=True,
+                           text=True, cwd=ROOT, env=clean_env(), timeout=900)
+        assert r.returncode == want, (r.returncode, r.stderr[-2000:])
+        d = one_json_line(r.stdout)
+        assert d["value"] > 0 and d["roofline"]["frac"] > 0 and d["extras_watchdog"] is True
+    last = d["configs"][-1]
+    assert "watchdog" in last["error"] and last["running_phase"] and last["seconds_in_phase"] is not None

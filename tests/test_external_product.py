@@ -1,6 +1,8 @@
 """Fused mul_accumulate chain (cntt_prime*_external_product_batch) against the oracle's
-fwd / mul_accumulate / inv called in sequence (src/prime64.rs:794, :1085-1128, :872).  Covers the fused kernel
-(n <= 1024 u64 / <= 4096 u32, nout <= 4), the composed path (larger n, nout = 5), every arithmetic class,
+fwd / mul_accumulate / inv called in sequence (src/prime64.rs:794, :1085-1128, :872).  Covers the fused kernels (persistent
+walk with an LDS twiddle image up to n = 2048 u64 / 4096 u32, wave-block walk for u64 n = 4096 ... 16384, one element per
+workgroup for u32 n = 8192 ... 32768; nout <= 4 -- three / four outputs of the largest size of each width as two launches
+of <= 2 outputs), the composed path (single-pass sizes, nout = 5, the Montgomery class at large n), every arithmetic class,
 ragged batches, accumulate mode and the empty sum.  Bit-exact."""
 import numpy as np
 import pytest
@@ -47,7 +49,7 @@ CASES = [
     (64, 256, P63, 2, 3, 9),         # fused, strict class, several polynomials per workgroup with a ragged tail
     (64, 512, SOLINAS, 4, 1, 3),     # fused, generic (Montgomery) class
     (64, 16, P62, 2, 2, 3),          # single-pass transform: composed path
-    (64, 2048, P62, 3, 2, 2),        # beyond the fused sizes for u64: composed path
+    (64, 2048, P62, 3, 2, 2),        # two wavefronts per element
     (64, 1024, P62, 2, 5, 2),        # nout = 5: composed path
     (32, 1024, P30, 6, 2, 5),        # fused u32
     (32, 4096, P31, 2, 2, 3),        # fused u32, 32 registers per thread
@@ -57,8 +59,10 @@ CASES = [
     (32, 16384, P30, 3, 2, 3),
     (32, 16384, P32, 2, 3, 2),       # p >= 2^31 on doubles
     (32, 32768, P30, 2, 2, 2),
-    (32, 32768, P32, 2, 1, 1),       # Montgomery class at this size
-    (32, 32768, P30, 2, 3, 1),       # ... three outputs at n = 32768: composed path
+    (32, 32768, P32, 2, 1, 1),       # p >= 2^31 at this size (Montgomery class until round 3, doubles since)
+    (32, 32768, P30, 2, 3, 1),       # ... three / four outputs at n = 32768: two fused launches of <= 2 outputs (round 4)
+    (32, 32768, P30, 3, 4, 2),
+    (32, 32768, P32, 2, 3, 1),       # p >= 2^31 at this size: on doubles since round 4
     # the chain on the wave-block walk (ExtBlk): u64 n = 4096 / 8192 (1 .. 4 outputs) and 16384 (1 .. 2), every class but the Montgomery one
     (64, 4096, P62, 3, 2, 3),
     (64, 4096, P62, 2, 1, 2),
@@ -75,7 +79,11 @@ CASES = [
     (64, 16384, 1125899904679937, 9, 2, 2),     # CLS_FP: more terms than the accumulator's reduction period
     (64, 16384, SOLINAS, 2, 2, 1),
     (64, 16384, P63, 2, 1, 2),
-    (64, 16384, P62, 2, 3, 1),                  # ... three outputs: composed path
+    (64, 16384, P62, 2, 3, 1),                  # ... three / four outputs: two fused launches of <= 2 outputs (round 4)
+    (64, 16384, P62, 3, 4, 2),
+    (64, 16384, 1125899904679937, 9, 4, 1),     # CLS_FP, split launches, more terms than the accumulator's reduction period
+    (64, 16384, SOLINAS, 2, 3, 2),
+    (64, 16384, 9224497936763846657, 2, 3, 1),  # Montgomery class at this size: no fused kernel at all, composed path
     # three / four 64-bit accumulator tiles: the shapes that run without the next-term prefetch (ExtWp NEXT = false) ...
     (64, 2048, P62, 3, 3, 3),
     (64, 2048, P63, 2, 4, 2),

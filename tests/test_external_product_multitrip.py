@@ -105,6 +105,8 @@ CASES = [
     (64, 8192, SOLINAS, 2, 1, "blk"),
     (64, 16384, P62, 2, 2, "blk"),
     (64, 16384, FP51, 2, 1, "blk"),
+    (64, 16384, P62, 2, 4, "blk"),     # four outputs at this size: TWO launches of the two-output kernel over the same batch
+    (64, 16384, SOLINAS, 2, 3, "blk"),
 ]
 
 

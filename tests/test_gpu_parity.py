@@ -176,6 +176,35 @@ def test_boundary_inputs(plans, oplans):
                 assert np.array_equal(got, want), (bits, n, p, name)
 
 
+def test_words_outside_the_input_contract_do_not_fault(plans, oplans):
+    """The documented behaviour for coefficients >= modulus (include/cntt.h): the transforms neither reject nor
+    reduce them -- the lazy classes skip the first stage's conditional subtraction on the strength of the contract -- so the
+    polynomial they sit in comes out as unspecified residues; the call must complete, and the OTHER polynomials of the batch
+    must be exactly what they are without the offender (no state leaks between polynomials)."""
+    import torch
+    for bits, n, p in ((64, 1024, P62), (32, 1024, 1062862849), (64, 4096, P62), (32, 8192, 1062862849)):
+        plan, oplan = plans(bits, n, p), oplans(bits, n, p)
+        dt, tdt = (np.uint64, torch.int64) if bits == 64 else (np.uint32, torch.int32)
+        batch = 5
+        a = np.array([(i * 0x9E3779B97F4A7C15) % p for i in range(batch * n)], dtype=dt)
+        bad = a.copy()
+        top = (1 << bits) - 1
+        bad[2 * n:3 * n] = np.array([p, p + 1, 2 * p if 2 * p <= top else top, top] * (n // 4), dtype=dt)   # polynomial 2: all outside
+        want = a.copy()
+        for i in range(batch):
+            oplan.fwd(want[i * n:(i + 1) * n])
+        d = torch.from_numpy(bad.view(np.int64 if bits == 64 else np.int32).copy()).cuda()
+        plan.fwd_batch(d)      # completes
+        got = d.cpu().numpy().view(dt)
+        for i in (0, 1, 3, 4):
+            assert np.array_equal(got[i * n:(i + 1) * n], want[i * n:(i + 1) * n]), (bits, n, i)
+        plan.inv_batch(d)      # and the inverse of whatever came out completes too
+        torch.cuda.synchronize()
+        with pytest.raises(Exception):
+            plan.check_canonical(bad)
+        plan.check_canonical(a)
+
+
 def test_pointwise_golden_and_oracle(golden, oracle, plans, oplans):
     for ent in golden["pointwise"]:
         bits, n, p, seed = ent["bits"], ent["n"], ent["p"], ent["seed"]

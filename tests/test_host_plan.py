@@ -115,6 +115,22 @@ def test_native_plans_host_side():
         assert cls.try_new(48) is None
 
 
+def test_ew_grid_stays_below_the_dispatch_limit():
+    """Grid of the element-wise kernels (fill, split, CRT, pointwise, global stages): one 256-thread block per 256 work items, but
+    never more than a dispatch can hold -- 2^32 - 1 work-items per dimension, i.e. fewer than 2^24 blocks (the
+    round-3 cap of 2^30 blocks made every launch over 2^32 items fail with hipErrorInvalidConfiguration; 16 GiB of u32 is a
+    plausible fill on a 288 GB part).  The kernels are grid-stride with 64-bit indices, so the capped grid covers any count."""
+    import ctypes
+    f = cntt.lib().cntt_ew_grid
+    f.restype, f.argtypes = ctypes.c_uint, [ctypes.c_size_t]
+    for count in (1, 255, 256, 257, 65536 * 1024, (2**24 - 1) * 256, (2**24 - 1) * 256 + 1, 2**32 - 1, 2**32, 2**32 + 1, 2**34, 2**36,
+                  2**40):
+        g = f(count)
+        assert 1 <= g <= 2**24 - 1 and g * 256 <= 2**32 - 1, (count, g)
+        if count <= (2**24 - 1) * 256:
+            assert g == (count + 255) // 256, (count, g)
+
+
 def test_no_gpu_means_loud_failure():
     if cntt.device_count() > 0:
         pytest.skip("a GPU is present")
@@ -142,7 +158,11 @@ def test_async_load_kernels_do_not_spill(tmp_path):
     import shutil
     import subprocess
     llvm = "/opt/rocm/lib/llvm/bin"
-    assert os.path.exists(os.path.join(llvm, "clang-offload-bundler")), "ROCm LLVM tools not present"
+    if not os.path.exists(os.path.join(llvm, "clang-offload-bundler")):
+        # a box without the ROCm toolchain cannot read the code objects: skip THERE -- wherever the tools exist
+        # (the build image, the GPU box) missing objects still fail below; CNTT_REQUIRE_CODE_OBJECTS=1 turns the skip into a failure
+        assert os.environ.get("CNTT_REQUIRE_CODE_OBJECTS") != "1", "ROCm LLVM tools not present"
+        pytest.skip("ROCm LLVM tools not present on this machine")
     objdir = os.path.join(ROOT, "concrete-ntt_amd", "csrc", "_obj")
     checked, exempt = 0, 0
     for unit in ("ntt_inst_u64_fwd", "ntt_inst_u64_inv", "ntt_inst_u32_fwd", "ntt_inst_u32_inv", "ntt_inst_u64_mul",

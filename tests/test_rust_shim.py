@@ -212,3 +212,17 @@ def test_prime_and_product_modules_mirror_the_reference():
     for mod in ("prime32", "prime64", "native32", "native64", "native128", "native_binary32", "native_binary64", "native_binary128",
                 "product"):
         assert re.search(r"^pub mod %s \{" % mod, lib, flags=re.M), mod
+
+
+def test_borrowed_sub_plans_carry_the_parent_lifetime():
+    """ntt_0() .. of the native plans and plan_32() / plan_64() of the product plan hand out handles into the
+    parent's C++ object; the reference returns `&Plan`.  The shim must tie them to the borrow of the parent (PlanRef<'_>), never
+    return an owned-typed `Plan` that safe code could keep after dropping the parent."""
+    import re
+    src = open(os.path.join(ROOT, "rust", "src", "lib.rs")).read()
+    assert "pub struct PlanRef<'a>" in src and "PhantomData<&'a ()>" in src and "impl<'a> core::ops::Deref for PlanRef<'a>" in src
+    assert re.search(r"pub fn \$acc\(&self\) -> \$sub::PlanRef<'_>", src)
+    assert re.search(r"pub fn plan_32\(&self\) -> Vec<prime32::PlanRef<'_>>", src)
+    assert re.search(r"pub fn plan_64\(&self\) -> Vec<prime64::PlanRef<'_>>", src)
+    # the only constructor of a non-owning Plan is the unsafe one that returns a PlanRef
+    assert src.count("owned: false") == 1 and "pub(crate) unsafe fn borrowed<'a>" in src

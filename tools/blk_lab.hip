@@ -2,7 +2,7 @@
 // Composes the product's own NttBlk::run under shader-clock stamps; -DCNTT_BLK_LAB=<bits> selects a timing-only
 // ablation (see ntt_blk.hpp), -DLAB_TWC=<n> the twiddle chunk.  Random twiddles: timing only, no result check here
 // (parity is tests/test_gpu_parity.py through the C ABI).
-// Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 [-DCNTT_BLK_LAB=1] tools/blk_lab.hip -o blk_lab
+// Build: tools/lab_build.sh blk [-DCNTT_BLK_LAB=1 ...]   (the switches live in tools/blk_lab.patch, not in the product header)
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -25,7 +25,7 @@ __device__ __forceinline__ void lab_stamp(int k) {
 }
 #define CNTT_BLK_STAMP(k) lab_stamp(k)
 #endif
-#include "../concrete-ntt_amd/csrc/ntt_blk.hpp"
+#include "ntt_blk.hpp"   // a scratch copy with tools/blk_lab.patch applied (tools/lab_build.sh)
 using namespace cntt;
 __device__ unsigned long long lab_phase[10];
 

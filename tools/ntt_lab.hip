@@ -5,14 +5,14 @@
 //     LDS exchange, first-stage (uniform) twiddles only -- the VALU ceiling of the transform;
 //   * the product's persistent kernel wrapped with shader-clock / real-time stamps (s_memtime / s_memrealtime);
 //   * the persistent kernel checked bit for bit against the one-polynomial-per-workgroup kernel.
-// Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 tools/ntt_lab.hip -o ntt_lab
+// Build: tools/lab_build.sh ntt [flags]   |   tools/lab_build.sh xlane (-DCNTT_LAB_XLANE on a patched header copy)
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
 #include <cstdio>
 #include <vector>
 
-#include "../concrete-ntt_amd/csrc/ntt_kernel.hpp"
+#include "ntt_kernel.hpp"   // the product header, or (ntt_lab_xlane) a scratch copy with tools/xlane_lab.patch applied
 using namespace cntt;
 
 static uint64_t *g_data;

@@ -85,11 +85,13 @@ if __name__ == "__main__":
     prime(prime64, 64, 1024, SOLINAS, 65536)   # generic class
     prime(prime32, 32, 1024, P30, 131072)
     prime(prime32, 32, 16384, P30, 8192)        # ntt_kernel (one polynomial per workgroup), mul_kernel_one
-    native(native64.Plan32, 4096, 16384, False)          # C3
-    native(native_binary64.Plan32, 2048, 65536, True)    # C5
-    native(native64.Plan32, 8192, 4096, False)           # native_polymul_kernel<1, 13, 512> (LDS-parked tiles, one workgroup per CU)
+    native(native64.Plan32, 4096, 16384, False)          # C3: native_polymul_kernel_acc<1, 12, 256> (round 4: accumulating CRT, nothing parked)
+    native(native_binary64.Plan32, 2048, 65536, True)    # C5: native_polymul_kernel_acc<4, 11, 256>
+    native(native64.Plan32, 8192, 4096, False)           # native_polymul_kernel_acc<1, 13, 512> (one product per 512-thread workgroup)
+    native(native64.Plan32, 16384, 2048, False)          # native_polymul_kernel_acc<1, 14, 1024>
     native(native64.Plan32, 32768, 1024, False)          # native_polymul_kernel_g<1, 15> (persistent, global parking, 32 coefficients per thread)
     chain(1024, P62, 6, 2, 8192)                          # ext_kernel_wp
     chain(4096, P62, 6, 2, 2048)                          # ext_kernel_blk
     chain(1024, P62, 6, 4, 4096)                          # ext_kernel_wp, four outputs (no next-term prefetch)
+    chain(16384, P62, 6, 4, 512)                          # ext_kernel_blk<u64, 14, ..., 2> twice (four outputs as two launches)
     prod_plan(2048, [4294955009, 4294914049], 32768)      # product_fused

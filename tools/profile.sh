@@ -19,4 +19,9 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_I
   echo "== pmc $pass" | tee -a $R/gpurun_out/progress.log
   timeout -k 10 300 rocprofv3 --pmc $pass --output-format csv -d $OUT/pmc_$name -- python3 $ZOO > $OUT/pmc_$name.log 2>&1; echo "pmc rc=$?" | tee -a $R/gpurun_out/progress.log
 done
-cd $R && python3 tools/summarize_prof.py $OUT > $OUT/summary.txt 2>&1; python3 tools/summarize_prof.py $OUT --json --stamp $(python3 tools/csrc_hash.py) > $OUT/pmc_traffic.json 2>/dev/null; tail -40 $OUT/summary.txt
+cd $R
+# the stamp is the hash compiled into the LIBRARY THE PASSES LOADED (cntt_version(): concrete_ntt_amd.build_info()), not a hash of the
+# source tree next to it: bench.py compares it with the library it runs and flags a stale profile
+STAMP=$(python3 -c "import concrete_ntt_amd as c; print(c.build_info()['csrc_hash'])" 2>/dev/null | tail -1)
+python3 tools/trace_gaps.py $OUT/trace > $OUT/unfused_step_gaps.txt 2>&1
+python3 tools/summarize_prof.py $OUT > $OUT/summary.txt 2>&1; python3 tools/summarize_prof.py $OUT --json --stamp "$STAMP" > $OUT/pmc_traffic.json 2>/dev/null; tail -40 $OUT/summary.txt; cat $OUT/unfused_step_gaps.txt
