@@ -144,12 +144,30 @@ BLK_PASSES = [(0x381, 0x380), (0x78, 0x78), (0x207, 0x7)]   # the (64, 10) forwa
 BLK_PAD = (5, 2)
 
 
+# 32-bit words (round 4), N = 8192 ... 32768: 2048-word blocks, 32 coefficients per thread -- the (32, 11) schedule inside a
+# wavefront, the top LOGN - 11 stages before it.  Padding (7, 4): four words behind every 128 (3 % more LDS: 132 KiB at N = 32768),
+# a multiple of four words so that 16-byte accesses stay aligned; score() 13 over the twelve access sets of both directions.
+BLK32_LOGN = 11
+BLK32_PASSES = [(0x703, 0x700), (0xf8, 0xf8), (0x607, 0x7)]   # the (32, 11) forward schedule
+BLK32_PAD = (7, 4)
+
+
 def fam2_supported(bits, logn):
-    return bits == 64 and 12 <= logn <= 14
+    return (bits == 64 and 12 <= logn <= 14) or (bits == 32 and 13 <= logn <= 15)
 
 
 def make_sched_fam2(bits, logn, inv):
     assert fam2_supported(bits, logn)
+    if bits == 32:
+        top = logn - BLK32_LOGN
+        gm0 = ((1 << top) - 1) << BLK32_LOGN
+        # the other 5 - top register bits: bits 0, 1 (16-byte accesses), then the bit just below the block boundary
+        extra = [0, 1, 10][:5 - top]
+        rm0 = gm0 | sum(1 << b for b in extra)
+        passes = [(rm0, gm0)] + BLK32_PASSES
+        if inv:
+            passes = passes[::-1]
+        return Sched(bits, logn, inv, 5, passes, [], 1 << (logn - 5), BLK32_PAD)
     top = logn - BLK_LOGN                       # stages of the first pass
     gm0 = ((1 << top) - 1) << BLK_LOGN
     # the other 4 - top register bits: bit 0 (16-byte accesses), then the bits just below the block boundary

@@ -29,15 +29,17 @@ template <class T, int LOGN, bool INV, int CLS, int TWC = 2, bool SUB = false>
 struct NttBlk {
     using B = NttKernel<T, LOGN, INV, CLS, SUB, 2>;
     using S = typename B::S;
-    static_assert(sizeof(T) == 8 && B::NPASS == 4 && B::LOGE == 4, "wave-block schedules: 64-bit words, four passes of 16");
+    // 64-bit words: 1024-word blocks, 16 coefficients per thread; 32-bit words (round 4): 2048-word blocks, 32 per thread
+    static_assert(B::NPASS == 4 && B::LOGE == (sizeof(T) == 8 ? 4 : 5), "wave-block schedules: four passes, 8 KiB per wavefront");
     static constexpr int E = B::E, TPP = B::TPP, WPB = B::TPP;
     static constexpr uint32_t FULL = B::FULL;
-    static constexpr uint32_t BLK_IO = 0x381u;  // a wavefront's block, 16 bytes per lane on consecutive addresses
+    static constexpr uint32_t BLKMASK = sizeof(T) == 8 ? 0x3ffu : 0x7ffu;   // index bits inside a wavefront's block
+    static constexpr uint32_t BLK_IO = sizeof(T) == 8 ? 0x381u : 0x703u;   // a wavefront's block, 16 bytes per lane on consecutive addresses
     static constexpr uint32_t RM0 = S::RMASK[0], RM1 = S::RMASK[1], RM2 = S::RMASK[2], RM3 = S::RMASK[3];
     static constexpr uint32_t LOAD_RM = INV ? BLK_IO : RM0;   // HBM layouts: the top pass reads / writes its own layout
     static constexpr uint32_t STORE_RM = INV ? RM3 : BLK_IO;
     static constexpr int HARD = INV ? 2 : 0;                  // the exchange after this pass crosses wavefronts
-    static_assert(((INV ? RM0 : RM3) & ~0x3ffu) == 0 && ((INV ? RM3 : RM0) >> 10) == (FULL >> 10), "block passes / top pass");
+    static_assert(((INV ? RM0 : RM3) & ~BLKMASK) == 0 && ((INV ? RM3 : RM0) & ~BLKMASK) == (FULL & ~BLKMASK), "block passes / top pass");
 
     template <uint32_t RM> static constexpr int nv() { return B::template vec_elems<RM>(); }
 
@@ -58,13 +60,15 @@ struct NttBlk {
     using Vec2 = __attribute__((ext_vector_type(2))) uint32_t;
     template <uint32_t RM> struct Pf {
         static constexpr int NV = nv<RM>(), NVEC = E / NV;
-        using V = typename std::conditional<NV == 2, Vec4, Vec2>::type;
+        static constexpr bool B16 = NV * sizeof(T) == 16;   // 16-byte loads (8-byte ones otherwise)
+        static_assert(NV * sizeof(T) == 16 || NV * sizeof(T) == 8, "prefetch vectors of 8 or 16 bytes");
+        using V = typename std::conditional<B16, Vec4, Vec2>::type;
         template <int JV = 0> static __device__ __forceinline__ void issue(V (&v)[NVEC], const T *tile, uint32_t voff) {
             if constexpr (JV < NVEC) {
                 constexpr uint32_t BYTE = cdep((uint32_t)(JV * NV), RM) * (uint32_t)sizeof(T);
                 constexpr uint32_t WIN = BYTE & ~4095u, IMM = BYTE & 4095u;
                 const char *base = reinterpret_cast<const char *>(tile) + WIN;
-                if constexpr (NV == 2)
+                if constexpr (B16)
                     asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(v[JV]) : "v"(voff), "s"(base), "n"(IMM) : "memory");
                 else
                     asm volatile("global_load_dwordx2 %0, %1, %2 offset:%3" : "=v"(v[JV]) : "v"(voff), "s"(base), "n"(IMM) : "memory");
@@ -90,8 +94,19 @@ struct NttBlk {
         static __device__ __forceinline__ void unpack(T (&r)[E], const V (&v)[NVEC]) {
 #pragma unroll
             for (int j = 0; j < E; j += NV) {
-                r[j] = (T)v[j / NV][0] | ((T)v[j / NV][1] << 32);
-                if constexpr (NV == 2) r[j + 1] = (T)v[j / NV][2] | ((T)v[j / NV][3] << 32);
+                if constexpr (sizeof(T) == 8) {
+                    r[j] = (T)v[j / NV][0] | ((T)v[j / NV][1] << 32);
+                    if constexpr (NV == 2) r[j + 1] = (T)v[j / NV][2] | ((T)v[j / NV][3] << 32);
+                } else {
+                    // explicit moves AFTER the wait (NttKernel::unpack_async: a plain copy lets hipcc satisfy the wait statement's tied
+                    // operand by copying the not-yet-landed destination register before the s_waitcnt)
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) {
+                        uint32_t x;
+                        asm("v_mov_b32 %0, %1" : "=v"(x) : "v"(v[j / NV][i]));
+                        r[j + i] = (T)x;
+                    }
+                }
             }
         }
     };

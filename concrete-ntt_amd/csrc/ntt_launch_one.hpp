@@ -35,7 +35,13 @@ template <class K> static constexpr bool wp_eligible() {
 // (tests/test_host_plan.py and tests/test_async_load_guard.py check the code objects).
 // (The inverse of the strict class at N >= 8192 spilled at 128 VGPRs until the padded exchange layout freed the swizzle's
 // address registers: 112 VGPRs now, instantiated like the rest.)
+// Round 4: 32-bit words, N = 16384 / 32768 (2048-word blocks, 32 coefficients per thread).
 template <class T, int LOGN, bool INV, int CLS, bool SUB> static constexpr bool blk_eligible() {
+    // (the strict class's inverse and the double-precision class for p >= 2^31 want ~170 registers at 32 coefficients per thread --
+    // 20 ... 48 spilled next to the asynchronous prefetch: they stay on the plain one-polynomial-per-workgroup kernel)
+    // Measured against the plain kernel on one box (profiles/r04_blk32_vs_plain.txt): n = 16384 +10 % / +6 % (30-bit fwd / inv), +14 % (31-bit
+    // fwd); n = 32768 +12 % / +32 %, +28 %; n = 8192 -1 ... -4 % -- four 512-thread workgroups per CU already overlap there: not used.
+    if (sizeof(T) == 4) return !SUB && LOGN >= 14 && LOGN <= 15 && (CLS == CLS_LAZY || (CLS == CLS_STRICT && !INV));
     return sizeof(T) == 8 && !SUB && LOGN >= 12 && LOGN <= 14 && CLS != CLS_GENERIC;
 }
 // (double-buffered: 2 * TWC pairs are in flight; the forward kernels hold the prefetch across these passes, the inverse ones
@@ -62,8 +68,8 @@ static hipError_t launch_one(T *data, const TwPair<T> *tw, const ModParams<T> &P
             constexpr int BPC = BY_LDS < BY_WAVES ? BY_LDS : BY_WAVES;
             uint32_t grid = (uint32_t)num_cus() * BPC;
             if (grid > nsub) grid = nsub;
-            hipLaunchKernelGGL((ntt_kernel_blk<T, LOGN, INV, CLS, 4, blk_twc(LOGN, INV, CLS)>), dim3(grid), dim3(W::WPB), 0, stream,
-                               data, tw, P, nsub);
+            hipLaunchKernelGGL((ntt_kernel_blk<T, LOGN, INV, CLS, 4, (sizeof(T) == 4 ? 2 : blk_twc(LOGN, INV, CLS))>), dim3(grid),
+                               dim3(W::WPB), 0, stream, data, tw, P, nsub);
             return hipGetLastError();
         }
     }
