@@ -405,7 +405,14 @@ template <> struct AccWord<uint32_t> {
 };
 template <> struct AccWord<uint64_t> {
     using A = uint64_t;
-    static __device__ __forceinline__ A mad(A acc, uint32_t g, uint64_t lo, uint64_t) { return acc + (uint64_t)g * lo; }
+    // acc + g * lo (mod 2^64): one v_mad_u64_u32 for the low word of the constant, v_mul_lo_u32 + v_add_u32 for the high one (asm: left to
+    // itself hipcc turns the latter into a second v_mad_u64_u32 on a register pair it has to build and take apart with two moves)
+    static __device__ __forceinline__ A mad(A acc, uint32_t g, uint64_t lo, uint64_t) {
+        const uint64_t t = (uint64_t)g * (uint32_t)lo + acc;
+        uint32_t h;
+        asm("v_mul_lo_u32 %0, %1, %2" : "=v"(h) : "v"(g), "s"((uint32_t)(lo >> 32)));
+        return ((uint64_t)((uint32_t)(t >> 32) + h) << 32) | (uint32_t)t;
+    }
     static __device__ __forceinline__ void pin(A &acc) { asm volatile("" : "+v"(acc)); }
     static __device__ __forceinline__ uint64_t out(A acc, uint32_t k, uint64_t mlo, uint64_t) { return acc - (uint64_t)k * mlo; }
 };

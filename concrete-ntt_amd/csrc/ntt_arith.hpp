@@ -233,11 +233,15 @@ template <class T, int CLS> struct Bfly {
         }
     }
     // inverse (Gentleman-Sande): (x, y) <- (x + y, (x - y) w)
-    template <bool UNI = false>
+    // FIRST: the first stage of a stand-alone inverse transform -- x and y are memory words, canonical by the API's contract, so
+    // x + y < 2p already and the lazy class's conditional subtraction is left out (round 4; the fused kernels' inverse halves start
+    // from products in [0, 2p) and keep it)
+    template <bool UNI = false, bool FIRST = false>
     static __device__ __forceinline__ void inv(T &x, T &y, T w, T ws, const ModParams<T> &P) {
         if constexpr (CLS == CLS_LAZY) {
             const T d = (x + P.two_p) - y;
-            x = csub_two_p<T>(x + y, P.two_p, P.neg_two_p);
+            if constexpr (FIRST) x = x + y;
+            else x = csub_two_p<T>(x + y, P.two_p, P.neg_two_p);
             y = shoup_mul<T, UNI>(d, w, ws, P.neg_p);
         } else if constexpr (CLS == CLS_STRICT) {
             const T s = x + y;
@@ -322,11 +326,11 @@ template <int CLS> struct BoxOps {
         Y = box32((x << 1) + P.two_p - (uint32_t)X);            // x - t + 2p
     }
     // (x, y) <- (x + y, (x - y) w), values in [0, 2p)
-    template <bool UNI> static __device__ __forceinline__ void inv(uint64_t &X, uint64_t &Y, uint32_t w, uint32_t ws, const P32 &P) {
+    template <bool UNI, bool FIRST = false> static __device__ __forceinline__ void inv(uint64_t &X, uint64_t &Y, uint32_t w, uint32_t ws, const P32 &P) {
         const uint32_t x = (uint32_t)X, y = (uint32_t)Y;
         const uint32_t d = (x + P.two_p) - y;
         const uint32_t s = x + y;
-        X = box32(umin<uint32_t>(s, s - P.two_p));
+        X = box32(FIRST ? s : umin<uint32_t>(s, s - P.two_p));   // (FIRST: see Bfly::inv)
         const uint32_t q = __umulhi(d, ws);
         Y = mad_box<true>(q, P.neg_p, mul_box<UNI>(d, w));
     }
@@ -416,7 +420,7 @@ template <class T, int HEAD> struct BflyFp {
         x = Fp::u(__dadd_rn(xd, t));
         y = Fp::u(__dadd_rn(xd, -t));
     }
-    template <bool UNI = false>
+    template <bool UNI = false, bool FIRST = false>
     static __device__ __forceinline__ void inv(T &x, T &y, T w, T ws, const ModParams<T> &P) {
         const double xd = Fp::d(x), yd = Fp::d(y);
         x = Fp::u(__dadd_rn(xd, yd));
@@ -467,7 +471,7 @@ template <> struct BoxOps<CLS_FPW> {
         X = Fp::u(__dadd_rn(x, t));
         Y = Fp::u(__dadd_rn(x, -t));
     }
-    template <bool UNI> static __device__ __forceinline__ void inv(uint64_t &X, uint64_t &Y, uint32_t w, uint32_t ws, const P32 &P) {
+    template <bool UNI, bool FIRST = false> static __device__ __forceinline__ void inv(uint64_t &X, uint64_t &Y, uint32_t w, uint32_t ws, const P32 &P) {
         const double x = Fp::d(X), y = Fp::d(Y);
         X = Fp::u(__dadd_rn(x, y));
         Y = Fp::u(Fp::mul_data(__dadd_rn(x, -y), tw(w, ws), Fp::d(P.fp_p), Fp::d(P.fp_pinv)));
@@ -577,7 +581,7 @@ template <class T> struct Bfly<T, CLS_PM64> {
         const bool k = (s < x) | (s >= P.p);           // passed 2^64, or landed in [p, 2^64)
         return s + (k ? (T)P.pm_c : (T)0);             // - p
     }
-    template <bool UNI = false>
+    template <bool UNI = false, bool FIRST = false>
     static __device__ __forceinline__ void inv(T &x, T &y, T w, T, const ModParams<T> &P) {
         const T d = sub_c(x, y, P);
         x = add_canon(x, y, P);

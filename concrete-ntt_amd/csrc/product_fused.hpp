@@ -20,12 +20,12 @@ template <int LOGN, int CLS, int BLK>
 __global__ __launch_bounds__(BLK, 2) void product_fwd2_kernel(uint32_t *__restrict__ res32, const uint64_t *__restrict__ standard,
                                                               const ProductFusedTables F, const ProductArgs A, uint32_t batch,
                                                               uint32_t bounded) {
-    using Wf = NttWp<uint32_t, LOGN, false, CLS, BLK, 1>;
+    using Wf = NttWp<uint32_t, LOGN, false, CLS, BLK, 3>;   // family 3: 16 coefficients per thread, padded exchange layout (round 4)
     constexpr int E = Wf::E, TPP = Wf::TPP, NPASS = Wf::NPASS, PPB = BLK / TPP;
     constexpr uint32_t FULL = Wf::FULL, RM0 = Wf::S::RMASK[0], RML = Wf::S::RMASK[NPASS - 1];
-    __shared__ __attribute__((aligned(16))) uint32_t lds_all[(size_t)PPB << LOGN];
+    __shared__ __attribute__((aligned(16))) uint32_t lds_all[(size_t)PPB * Wf::B::LDS_WORDS_1];
     const uint32_t tid = threadIdx.x & (TPP - 1), pl = threadIdx.x / TPP;
-    uint32_t *lds = lds_all + ((size_t)pl << LOGN);
+    uint32_t *lds = lds_all + (size_t)pl * Wf::B::LDS_WORDS_1;
     const uint32_t sub = blockIdx.x * PPB + pl;
     const uint32_t subc = sub < batch ? sub : batch - 1;
     const uint64_t *sp = standard + ((size_t)subc << LOGN);
@@ -58,12 +58,12 @@ template <int LOGN, int CLS, int BLK>
 __global__ __launch_bounds__(BLK, 2) void product_inv2_kernel(uint64_t *__restrict__ standard, uint32_t *__restrict__ res32,
                                                               const ProductFusedTables F, const ProductArgs A, uint32_t batch,
                                                               uint32_t accumulate) {
-    using Wi = NttWp<uint32_t, LOGN, true, CLS, BLK, 1>;
+    using Wi = NttWp<uint32_t, LOGN, true, CLS, BLK, 3>;
     constexpr int E = Wi::E, TPP = Wi::TPP, NPASS = Wi::NPASS, PPB = BLK / TPP;
     constexpr uint32_t FULL = Wi::FULL, RM0 = Wi::S::RMASK[0], RML = Wi::S::RMASK[NPASS - 1];
-    __shared__ __attribute__((aligned(16))) uint32_t lds_all[(size_t)PPB << LOGN];
+    __shared__ __attribute__((aligned(16))) uint32_t lds_all[(size_t)PPB * Wi::B::LDS_WORDS_1];
     const uint32_t tid = threadIdx.x & (TPP - 1), pl = threadIdx.x / TPP;
-    uint32_t *lds = lds_all + ((size_t)pl << LOGN);
+    uint32_t *lds = lds_all + (size_t)pl * Wi::B::LDS_WORDS_1;
     const uint32_t sub = blockIdx.x * PPB + pl;
     const uint32_t subc = sub < batch ? sub : batch - 1;
     const uint32_t ebase0 = pdep<FULL & ~RM0>(tid), ebaseL = pdep<FULL & ~RML>(tid);
