@@ -195,6 +195,12 @@ template <class T, class PlanT> static int plan_new(size_t n, T p, PlanT **out) 
         mp.n_inv_shoup = pl->n_inv_shoup;
         mp.last_w = (T)w_last;
         mp.last_w_shoup = shoup_of<T>((T)w_last, p);
+        // the same two constants times 2^B: the fused product kernels of the lazy class multiply pointwise with a Montgomery product
+        // (ntt_arith.hpp mul_fused), whose 2^-B is undone where 1/N is applied
+        mp.mont_n_inv = (T)host::mulmod((uint64_t)pl->n_inv, r1, p64);
+        mp.mont_n_inv_shoup = shoup_of<T>(mp.mont_n_inv, p);
+        mp.mont_last_w = (T)host::mulmod(w_last, r1, p64);
+        mp.mont_last_w_shoup = shoup_of<T>(mp.mont_last_w, p);
     }
     // CLS_FP / CLS_FP51: 64-bit words, p < 2^50 / 2^51 (the classes of src/prime64/less_than_50bit.rs and
     // less_than_51bit.rs).  CNTT_DISABLE_FP=1 keeps such plans on the integer butterflies (A/B measurements, and tests

@@ -58,6 +58,9 @@ template <class T> struct ModParams {
     // CLS_PM64 (p = 2^64 - c, c < 2^32): c, and the plan constants as plain residues
     uint32_t pm_c;         // 0: not such a modulus
     T pm_n_inv, pm_last_w;
+    // lazy class, fused product kernels (round 4): N^-1 2^B and inv_twid[1] N^-1 2^B mod p with their Shoup companions -- the pointwise
+    // product between the transforms is a Montgomery product there (mul_fused) and leaves a factor 2^-B for the last inverse stage
+    T mont_n_inv, mont_n_inv_shoup, mont_last_w, mont_last_w_shoup;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -658,6 +661,42 @@ template <class T, int CLS> __device__ __forceinline__ T mul_for_inv(T a, T b, c
         return barrett_mul_lazy<T>(a, b, P);
     }
 }
+// ---------------------------------------------------------------------------------------------
+// The pointwise product INSIDE the fused product kernels (forward transform -> product -> inverse transform in registers; round 4).
+// Lazy class: a is the forward transform's lazy output in [0, 4p) -- its canonicalisation is skipped --, b a canonical word of rhs_ntt:
+// one conditional subtraction of 2p, then a Montgomery product  u = (a b + m p) / 2^B,  m = lo(a b) (-p^-1) mod 2^B:
+//     a < 2p, b < p, p < 2^(B-2)  =>  hi(a b) < p / 2,  hi(m p) < p,  u = hi(a b) + hi(m p) + [lo(a b) != 0] < 2p
+// (lo(a b) + lo(m p) = 0 mod 2^B, so the carry into the upper word is 1 exactly when lo(a b) != 0).  u = a b 2^-B mod p goes straight
+// into the inverse transform, whose last stage -- the one that applies 1/N (Bfly::inv_norm) -- takes constants multiplied by 2^B
+// (mul_inv_params): 24 instructions instead of 8 (canonicalisation) + 26 (Barrett, mul_for_inv) for 64-bit words, 5 instead of 9 for
+// 32-bit ones.  Every other class keeps mul_for_inv.
+// ---------------------------------------------------------------------------------------------
+template <int CLS> __host__ __device__ constexpr bool mul_is_mont() { return CLS == CLS_LAZY; }
+// FIN of the forward transform in front of mul_fused: does it have to canonicalise its outputs?
+template <class T, int CLS> __host__ __device__ constexpr bool mul_fwd_fin() { return !Bfly<T, CLS>::FUSED_LAZY && !mul_is_mont<CLS>(); }
+template <class T, int CLS> __device__ __forceinline__ T mul_fused(T a, T b, const ModParams<T> &P) {
+    if constexpr (mul_is_mont<CLS>()) {
+        a = csub_two_p<T>(a, P.two_p, P.neg_two_p);
+        T lo, hi;
+        Wide<T>::mul(a, b, lo, hi);
+        const T m = lo * P.pinv_neg;
+        return hi + mulhi(m, P.p) + (lo != 0 ? (T)1 : (T)0);
+    } else {
+        return mul_for_inv<T, CLS>(a, b, P);
+    }
+}
+// the parameters the inverse half of a fused product kernel runs on
+template <class T, int CLS> __device__ __forceinline__ ModParams<T> mul_inv_params(const ModParams<T> &P) {
+    ModParams<T> Q = P;
+    if constexpr (mul_is_mont<CLS>()) {
+        Q.n_inv = P.mont_n_inv;
+        Q.n_inv_shoup = P.mont_n_inv_shoup;
+        Q.last_w = P.mont_last_w;
+        Q.last_w_shoup = P.mont_last_w_shoup;
+    }
+    return Q;
+}
+
 template <class T> __device__ __forceinline__ T normalize1(T a, const ModParams<T> &P, bool generic) {
     if (generic) {
         // n_inv field = n_inv * R^2 ; mont(a, R^-1-free) : mont(a, n_inv R^2) = a n_inv R ; one more REDC by 1

@@ -392,7 +392,7 @@ struct MulBlk {
 #pragma unroll
             for (int j = 0; j < E; ++j) r[j] = Bfly<T, CLS>::load_fix(r[j], P);
             F::transform(r, lds, tidv, twf, P);
-            if constexpr (!Bfly<T, CLS>::FUSED_LAZY) {
+            if constexpr (mul_fwd_fin<T, CLS>()) {   // (lazy class: the Montgomery product below takes the lazy outputs, ntt_arith.hpp mul_fused)
 #pragma unroll
                 for (int j = 0; j < E; ++j) r[j] = Bfly<T, CLS>::finish_fwd(r[j], P);
             }
@@ -416,7 +416,7 @@ struct MulBlk {
                     asm volatile("" ::: "memory");
 #pragma unroll
                     for (int i = 0; i < CH; ++i) {
-                        r[C * CH + i] = mul_for_inv<T, CLS>(r[C * CH + i], bc[C & 1][i], P);  // 1/N: inside the last inverse stage
+                        r[C * CH + i] = mul_fused<T, CLS>(r[C * CH + i], bc[C & 1][i], P);  // 1/N: inside the last inverse stage
                         asm volatile("" : "+v"(r[C * CH + i]));
                     }
                 });
@@ -424,7 +424,7 @@ struct MulBlk {
             // the inverse starts in the wavefront's own block: nothing of another wavefront is touched until its transpose
             uint32_t ti = tidv;   // fresh opaque copy: no address of the forward half stays live into the inverse half
             asm volatile("" : "+v"(ti));
-            I::template transform<true>(r, lds, ti, twi, P, prefetch);
+            I::template transform<true>(r, lds, ti, twi, mul_inv_params<T, CLS>(P), prefetch);
 #pragma unroll
             for (int j = 0; j < E; ++j) r[j] = Bfly<T, CLS>::finish_inv(r[j], P);
             FB::template scatter_tile<RMIO>(r, tbase, pdep<CMIO>(tidv) * (uint32_t)sizeof(T));
@@ -471,7 +471,7 @@ struct Mul32k {
                                                 const TwPair<T> *__restrict__ twf, const TwPair<T> *__restrict__ twi,
                                                 const ModParams<T> &P, uint32_t qpre) {
         HF::template transform<false>(r, lds, tidv, twf, P, typename HF::NoHook{}, qpre);
-        if constexpr (!Bfly<T, CLS>::FUSED_LAZY) {
+        if constexpr (mul_fwd_fin<T, CLS>()) {
 #pragma unroll
             for (int j = 0; j < E; ++j) r[j] = Bfly<T, CLS>::finish_fwd(r[j], P);
         }
@@ -490,7 +490,7 @@ struct Mul32k {
                 asm volatile("" ::: "memory");
 #pragma unroll
                 for (int i = 0; i < CH; ++i) {
-                    r[C * CH + i] = mul_for_inv<T, CLS>(r[C * CH + i], bc[C & 1][i], P);
+                    r[C * CH + i] = mul_fused<T, CLS>(r[C * CH + i], bc[C & 1][i], P);
                     asm volatile("" : "+v"(r[C * CH + i]));
                 }
             });
@@ -536,7 +536,7 @@ struct Mul32k {
                     a[j] = Bfly<T, CLS>::reduce(a[j], P);
                     b[j] = Bfly<T, CLS>::reduce(b[j], P);
                 }
-                Bfly<T, CLS>::inv_norm(a[j], b[j], P);
+                Bfly<T, CLS>::inv_norm(a[j], b[j], mul_inv_params<T, CLS>(P));   // (lazy class: constants times 2^B, mul_fused)
                 a[j] = Bfly<T, CLS>::finish_inv(a[j], P);
                 b[j] = Bfly<T, CLS>::finish_inv(b[j], P);
             }

@@ -760,6 +760,7 @@ struct MulWp {
         FB::fill_image(imgf, twf);
         IB::fill_image(imgi, twi);
         __syncthreads();
+        const ModParams<T> Pi = mul_inv_params<T, CLS>(P);   // the inverse half's constants (lazy class: times 2^B, see mul_fused)
         const uint32_t tid = threadIdx.x & (TPP - 1);
         const uint32_t pl = threadIdx.x / TPP;
         T *lds = lds_all + (size_t)pl * FB::LDS_WORDS_1;
@@ -802,7 +803,7 @@ struct MulWp {
                 F::wsync();
             }
             // NTT-domain values in layout RMM: canonical, or (CLS_FP) the lazy doubles mul_for_inv takes
-            F::template pass<0, false, true, !Bfly<T, CLS>::FUSED_LAZY>(r, lds, tid, twf, imgf, P);
+            F::template pass<0, false, true, mul_fwd_fin<T, CLS>()>(r, lds, tid, twf, imgf, P);
             {
                 // clamped polynomial index for the reads of a ragged tail
                 const uint32_t lastc = nsub - 1u - tile * PPB;
@@ -811,10 +812,10 @@ struct MulWp {
                 FB::template gather_tile<RMM>(b, rhs_ntt + (((size_t)tile * PPB) << LOGN),
                                               ((plc << LOGN) + ebaseM) * (uint32_t)sizeof(T));
 #pragma unroll
-                for (int j = 0; j < E; ++j) r[j] = mul_for_inv<T, CLS>(r[j], b[j], P);  // 1/N: inside the last inverse stage
+                for (int j = 0; j < E; ++j) r[j] = mul_fused<T, CLS>(r[j], b[j], P);  // 1/N: inside the last inverse stage
             }
             F::wsync();  // the forward transform's last exchange has been read before the inverse overwrites it
-            I::template pass<0, true>(r, lds, tid, twi, imgi, P);  // canonical coefficients, layout RML
+            I::template pass<0, true>(r, lds, tid, twi, imgi, Pi);  // canonical coefficients, layout RML
             if constexpr (RML != IO_RM) {
                 F::wsync();
                 FB::template scatter<RML>(r, lds, ebaseL, true);
@@ -871,17 +872,17 @@ struct MulOne {
 #pragma unroll
         for (int j = 0; j < E; ++j) r[j] = Bfly<T, CLS>::load_fix(r[j], P);
         // NTT-domain values in layout RMM: canonical, or the lazy form mul_for_inv takes
-        F::template pass<0, false, false, !Bfly<T, CLS>::FUSED_LAZY>(r, lds, tid, twf, nullptr, P);
+        F::template pass<0, false, false, mul_fwd_fin<T, CLS>()>(r, lds, tid, twf, nullptr, P);
         {
             T b[E];
             FB::template gather_tile<RMM>(b, rhs_ntt + ((size_t)blockIdx.x << LOGN), pdep<CMM>(tid) * (uint32_t)sizeof(T));
 #pragma unroll
-            for (int j = 0; j < E; ++j) r[j] = mul_for_inv<T, CLS>(r[j], b[j], P);  // 1/N: inside the last inverse stage
+            for (int j = 0; j < E; ++j) r[j] = mul_fused<T, CLS>(r[j], b[j], P);  // 1/N: inside the last inverse stage
         }
         F::wsync();  // the forward transform's last exchange has been read before the inverse overwrites it
         uint32_t ti = tid;   // fresh opaque copy: no address of the forward half stays live into the inverse half
         asm volatile("" : "+v"(ti));
-        I::template pass<0, true, false>(r, lds, ti, twi, nullptr, P);  // canonical coefficients, layout RML
+        I::template pass<0, true, false>(r, lds, ti, twi, nullptr, mul_inv_params<T, CLS>(P));  // canonical coefficients, layout RML
         FB::template scatter<RML>(r, base, pdep<CML>(ti), false);
     }
 };
