@@ -663,12 +663,12 @@ template <class T, int CLS> __device__ __forceinline__ T mul_for_inv(T a, T b, c
 }
 // ---------------------------------------------------------------------------------------------
 // The pointwise product INSIDE the fused product kernels (forward transform -> product -> inverse transform in registers; round 4).
-// Lazy class: a is the forward transform's lazy output in [0, 4p) -- its canonicalisation is skipped --, b a canonical word of rhs_ntt:
-// one conditional subtraction of 2p, then a Montgomery product  u = (a b + m p) / 2^B,  m = lo(a b) (-p^-1) mod 2^B:
-//     a < 2p, b < p, p < 2^(B-2)  =>  hi(a b) < p / 2,  hi(m p) < p,  u = hi(a b) + hi(m p) + [lo(a b) != 0] < 2p
+// Lazy class: a is the forward transform's lazy output in [0, 4p) AS IT IS -- no canonicalisation, no conditional subtraction --, b a
+// canonical word of rhs_ntt; a Montgomery product  u = (a b + m p) / 2^B,  m = lo(a b) (-p^-1) mod 2^B:
+//     a < 4p < 2^B, b <= p - 1  =>  hi(a b) <= p - 1,  hi(m p) <= p - 1,  u = hi(a b) + hi(m p) + [lo(a b) != 0] <= 2p - 1
 // (lo(a b) + lo(m p) = 0 mod 2^B, so the carry into the upper word is 1 exactly when lo(a b) != 0).  u = a b 2^-B mod p goes straight
 // into the inverse transform, whose last stage -- the one that applies 1/N (Bfly::inv_norm) -- takes constants multiplied by 2^B
-// (mul_inv_params): 24 instructions instead of 8 (canonicalisation) + 26 (Barrett, mul_for_inv) for 64-bit words, 5 instead of 9 for
+// (mul_inv_params): 20 instructions instead of 8 (canonicalisation) + 26 (Barrett, mul_for_inv) for 64-bit words, 3 instead of 9 for
 // 32-bit ones.  Every other class keeps mul_for_inv.
 // ---------------------------------------------------------------------------------------------
 template <int CLS> __host__ __device__ constexpr bool mul_is_mont() { return CLS == CLS_LAZY; }
@@ -676,7 +676,6 @@ template <int CLS> __host__ __device__ constexpr bool mul_is_mont() { return CLS
 template <class T, int CLS> __host__ __device__ constexpr bool mul_fwd_fin() { return !Bfly<T, CLS>::FUSED_LAZY && !mul_is_mont<CLS>(); }
 template <class T, int CLS> __device__ __forceinline__ T mul_fused(T a, T b, const ModParams<T> &P) {
     if constexpr (mul_is_mont<CLS>()) {
-        a = csub_two_p<T>(a, P.two_p, P.neg_two_p);
         T lo, hi;
         Wide<T>::mul(a, b, lo, hi);
         const T m = lo * P.pinv_neg;

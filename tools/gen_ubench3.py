@@ -74,6 +74,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "mixed":   # mixed streams: do the doubl
      ("min ; sub vvv (2 instr)", "v_min_u32 %6, %6, %1\n\tv_sub_u32 %0, %0, %1", 32),
      ("min ; subrev svv (2 instr)", "v_min_u32 %6, %6, %1\n\tv_subrev_u32 %0, %3, %0", 32),
      ("add vvv ; add vvv (2 instr)", "v_add_u32 %6, %6, %1\n\tv_add_u32 %0, %0, %1", 32),
+     ("cmp_lt_u64 e32 vcc ; 2 cndmask e32 vcc (3 instr)", "v_cmp_lt_u64_e32 vcc, %5, %4\n\tv_cndmask_b32_e32 %0, %0, %1, vcc\n\tv_cndmask_b32_e32 %6, %6, %2, vcc", 32),
+     ("cmp_lt_u64 e64 s[] ; 2 cndmask e64 s[] (3 instr + nop)", "v_cmp_lt_u64_e64 s[10:11], %5, %4\n\ts_nop 1\n\tv_cndmask_b32_e64 %0, %0, %1, s[10:11]\n\tv_cndmask_b32_e64 %6, %6, %2, s[10:11]", 32),
      ("u32 fwd bfly sgpr 2p (7 instr)", "v_subrev_u32 %7, %3, %0\n\tv_min_u32 %0, %0, %7\n\tv_mul_hi_u32 %7, %6, %2\n\tv_mad_u64_u32 %5, vcc, %6, %1, %5\n\tv_mad_u64_u32 %5, vcc, %7, %3, %5\n\tv_lshl_add_u32 %7, %0, 1, %3\n\tv_sub_u32 %6, %7, %0", 32),
      ("u32 fwd bfly vgpr 2p (7 instr)", "v_sub_u32 %7, %0, %2\n\tv_min_u32 %0, %0, %7\n\tv_mul_hi_u32 %7, %6, %2\n\tv_mad_u64_u32 %5, vcc, %6, %1, %5\n\tv_mad_u64_u32 %5, vcc, %7, %3, %5\n\tv_lshl_add_u32 %7, %0, 1, %2\n\tv_sub_u32 %6, %7, %0", 32),
     ]
@@ -150,7 +152,7 @@ lines=[]
 for i,(name,asm,kind) in enumerate(ops):
     asm = asm.replace("\n", "\\n").replace("\t", "\\t")
     accv = "acc32[c]" if kind==32 else "acc[c]"
-    lines.append('                if constexpr (OP == %d) asm volatile("%s" : "+v"(%s) : "v"(a), "v"(b), "s"(s), "v"(w64), "v"(acc[c]), "v"(x32[c]), "v"(y32[c]) : "vcc");' % (i, asm, accv) if len(sys.argv) > 1 else
+    lines.append('                if constexpr (OP == %d) asm volatile("%s" : "+v"(%s) : "v"(a), "v"(b), "s"(s), "v"(w64), "v"(acc[c]), "v"(x32[c]), "v"(y32[c]) : "vcc", "s10", "s11");' % (i, asm, accv) if len(sys.argv) > 1 else
                  '                if constexpr (OP == %d) asm volatile("%s" : "+v"(%s) : "v"(a), "v"(b), "s"(s), "v"(w64) : "vcc");' % (i, asm, accv))
 src=src.replace("OPS","\n".join(lines)).replace("NAMELIST", ", ".join('"%s"'%o[0] for o in ops)).replace("RUNS","\n".join("    run<%d>(sink, cyc);"%i for i in range(len(ops))))
 open("/root/repo/tools/ubench3%s.hip" % ("m" if len(sys.argv) > 1 else ""),"w").write(src)
