@@ -201,6 +201,8 @@ template <class T, class PlanT> static int plan_new(size_t n, T p, PlanT **out) 
         mp.mont_n_inv_shoup = shoup_of<T>(mp.mont_n_inv, p);
         mp.mont_last_w = (T)host::mulmod(w_last, r1, p64);
         mp.mont_last_w_shoup = shoup_of<T>(mp.mont_last_w, p);
+        mp.mont_r = (T)r1;   // the fused mul_accumulate chains multiply their accumulators by 2^B once (ntt_arith.hpp chain_pre_inverse)
+        mp.mont_r_shoup = shoup_of<T>(mp.mont_r, p);
     }
     // CLS_FP / CLS_FP51: 64-bit words, p < 2^50 / 2^51 (the classes of src/prime64/less_than_50bit.rs and
     // less_than_51bit.rs).  CNTT_DISABLE_FP=1 keeps such plans on the integer butterflies (A/B measurements, and tests

@@ -61,6 +61,7 @@ template <class T> struct ModParams {
     // lazy class, fused product kernels (round 4): N^-1 2^B and inv_twid[1] N^-1 2^B mod p with their Shoup companions -- the pointwise
     // product between the transforms is a Montgomery product there (mul_fused) and leaves a factor 2^-B for the last inverse stage
     T mont_n_inv, mont_n_inv_shoup, mont_last_w, mont_last_w_shoup;
+    T mont_r, mont_r_shoup;   // 2^B mod p and its Shoup companion: the fused mul_accumulate chains undo their products' 2^-B with it
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -671,6 +672,11 @@ template <class T, int CLS> __device__ __forceinline__ T mul_for_inv(T a, T b, c
 // (mul_inv_params): 20 instructions instead of 8 (canonicalisation) + 26 (Barrett, mul_for_inv) for 64-bit words, 3 instead of 9 for
 // 32-bit ones.  Every other class keeps mul_for_inv.
 // ---------------------------------------------------------------------------------------------
+// NOT the strict class (2^(B-2) <= p < 2^(B-1)), although the same product would be valid there (a < 2p <= 2^B): the reference's Barrett
+// product (src/prime32.rs mul_assign_normalize / mul_accumulate, src/prime64.rs likewise) leaves d - c3 p in [0, 3p) and keeps its low
+// B bits; for p > 2^B / 3 that remainder can pass 2^B, and the reference's result is then off by 2^B mod p (measured: 7e-4 of the products
+// for p = 2127586817, 5e-6 for p = 1896656897).  barrett_mul_lazy reproduces that bit for bit, an exact product does not
+// (tests/test_gpu_parity.py::test_strict_class_keeps_the_reference_barrett_wrap), so the strict class keeps mul_for_inv / mul_acc.
 template <int CLS> __host__ __device__ constexpr bool mul_is_mont() { return CLS == CLS_LAZY; }
 // FIN of the forward transform in front of mul_fused: does it have to canonicalise its outputs?
 template <class T, int CLS> __host__ __device__ constexpr bool mul_fwd_fin() { return !Bfly<T, CLS>::FUSED_LAZY && !mul_is_mont<CLS>(); }
@@ -683,6 +689,11 @@ template <class T, int CLS> __device__ __forceinline__ T mul_fused(T a, T b, con
     } else {
         return mul_for_inv<T, CLS>(a, b, P);
     }
+}
+// an accumulator of the fused chains -> what the inverse transform's first stage accepts (Montgomery classes: times 2^B, in [0, 2p))
+template <class T, int CLS> __device__ __forceinline__ T chain_pre_inverse(T v, const ModParams<T> &P) {
+    if constexpr (mul_is_mont<CLS>()) return shoup_mul<T, true>(v, P.mont_r, P.mont_r_shoup, P.neg_p);
+    else return Bfly<T, CLS>::pre_inverse(v, P);
 }
 // the parameters the inverse half of a fused product kernel runs on
 template <class T, int CLS> __device__ __forceinline__ ModParams<T> mul_inv_params(const ModParams<T> &P) {
@@ -719,7 +730,17 @@ template <class T> __device__ __forceinline__ T mul_acc(T acc, T a, T b, const M
 // acc + a * b in the accumulator form of class CLS (the fused mul_accumulate chains): the integer classes keep
 // canonical accumulators; the double classes add the product (|.| <= 0.875 p, `a` already range-reduced) to a lazy double.
 template <class T, int CLS> __device__ __forceinline__ T mul_acc_cls(T acc, T a, T b, const ModParams<T> &P) {
-    if constexpr (CLS == CLS_PM64) {
+    if constexpr (mul_is_mont<CLS>()) {
+        // round 4: a is the forward transform's lazy output (no canonicalisation), the product a Montgomery product u < 2p (mul_fused),
+        // the accumulator lives in [0, 2p): one conditional subtraction of 2p per term.  The factor 2^-B common to every term is undone
+        // once per output coefficient in front of the inverse transform (chain_pre_inverse): 25 instructions per term, output and
+        // coefficient instead of 8 / J + 35 for 64-bit words, 6 instead of 10 for 32-bit ones.
+        T lo, hi;
+        Wide<T>::mul(a, b, lo, hi);
+        const T m = lo * P.pinv_neg;
+        const T u = hi + mulhi(m, P.p) + (lo != 0 ? (T)1 : (T)0);
+        return csub_two_p<T>(acc + u, P.two_p, P.neg_two_p);   // 4p < 2^B: no wrap
+    } else if constexpr (CLS == CLS_PM64) {
         return Bfly<T, CLS>::add_c(acc, Bfly<T, CLS>::template mulc<false>(a, b, P), P);
     } else if constexpr (is_fp_class(CLS)) {
         const double p = Fp::d(P.fp_p), pinv = Fp::d(P.fp_pinv);

@@ -616,7 +616,7 @@ struct ExtBlk {
 #pragma unroll
                 for (int e = 0; e < E; ++e) r[e] = Bfly<T, CLS>::load_fix(r[e], P);
                 F::transform(r, lds, tj, twf, P);   // (its first exchange waits for everybody's last read of the buffer)
-                if constexpr (!Bfly<T, CLS>::FUSED_LAZY) {
+                if constexpr (mul_fwd_fin<T, CLS>()) {
 #pragma unroll
                     for (int e = 0; e < E; ++e) r[e] = Bfly<T, CLS>::finish_fwd(r[e], P);
                 }
@@ -637,7 +637,7 @@ struct ExtBlk {
             static_for<0, NOUT>([&](auto o) {
                 T(&a)[E] = acc[o.value];
 #pragma unroll
-                for (int e = 0; e < E; ++e) a[e] = Bfly<T, CLS>::pre_inverse(a[e], P);  // lazy accumulator -> inverse input
+                for (int e = 0; e < E; ++e) a[e] = chain_pre_inverse<T, CLS>(a[e], P);  // lazy accumulator -> inverse input
                 // the inverse starts by writing the wavefront's own block: everybody must have finished the previous
                 // output's cross-wave gather (or the last forward transform never left the block: harmless extra wait)
                 F::template xsync<false>();

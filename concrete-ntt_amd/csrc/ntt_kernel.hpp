@@ -969,11 +969,13 @@ struct ExtWp {
         // used and recompute their layout / image offsets per term from an opaque copy of the thread index (hoisted out
         // of the term loop they stay live next to the accumulators).  Measured with tools/ext_bench.py (J = 6, N = 512 ...
         // 2048): four outputs -22 ... -45 % in every class; three outputs -18 ... -23 % for p = 2^64 - c, -10 ... -13 % for
-        // the 62- / 63-bit classes at N = 2048, but +9 ... +19 % for them below and +4 ... +7 % for the double-precision
-        // classes, which keep the prefetch there.
+        // the 63-bit class at N = 2048, but +9 ... +19 % for it below and +4 ... +7 % for the double-precision
+        // classes, which keep the prefetch there.  The 62-bit class with three outputs, re-measured in round 4 on the Montgomery
+        // accumulate (whose 128-bit intermediates made the prefetching shape spill 41 ... 57 registers): -13 ... -24 % at
+        // N = 256 ... 1024, -5 % at N = 128, +-1 % at N = 64, +6 % at N = 32 (which keeps the prefetch).
         constexpr bool NEXT = !(sizeof(T) == 8 &&
-                                (NOUT == 4 || (NOUT == 3 && (CLS == CLS_PM64 || CLS == CLS_GENERIC ||
-                                                             (LOGN >= 11 && (CLS == CLS_LAZY || CLS == CLS_STRICT))))));
+                                (NOUT == 4 || (NOUT == 3 && (CLS == CLS_PM64 || CLS == CLS_GENERIC || (LOGN >= 7 && CLS == CLS_LAZY) ||
+                                                             (LOGN >= 11 && CLS == CLS_STRICT)))));
         constexpr bool OPAQUE = !NEXT;   // (with the prefetch kept, recomputing per term measured +-0 ... +6 %: not used there)
         for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
             const uint32_t b = tile * PPB + pl;
@@ -1003,12 +1005,14 @@ struct ExtWp {
                     F::wsync();
                 }
                 // NTT-domain values in layout RMM: canonical, or (CLS_FP) range-reduced doubles
-                F::template pass<0, false, true, !Bfly<T, CLS>::FUSED_LAZY>(r, lds, tj, twf, imgf, P);
+                F::template pass<0, false, true, mul_fwd_fin<T, CLS>()>(r, lds, tj, twf, imgf, P);
                 if constexpr (Bfly<T, CLS>::IS_FP) {
 #pragma unroll
                     for (int e = 0; e < E; ++e) r[e] = Bfly<T, CLS>::reduce(r[e], P);
                 }
                 const uint32_t ebM = !OPAQUE ? ebaseM : pdep<CMM>(tj);
+                // (the Montgomery products kept behind the transform: overlapped with its last stage the one-output shapes spill)
+                if constexpr (sizeof(T) == 8 && mul_is_mont<CLS>()) __builtin_amdgcn_sched_barrier(0);
                 static_for<0, NOUT>([&](auto o) {
                     mul_acc_key(acc[o.value], r, key_ntt + (((size_t)j * ostride + o.value) << LOGN), ebM, P);
                     if constexpr (Bfly<T, CLS>::IS_FP) {  // every product adds at most 0.875 p to the lazy accumulator
@@ -1030,7 +1034,7 @@ struct ExtWp {
                 if constexpr (OPAQUE) asm volatile("" : "+v"(to));
                 const uint32_t ebIO = !OPAQUE ? ebaseIO : pdep<CMIO>(to), ebL = !OPAQUE ? ebaseL : pdep<CML>(to);
 #pragma unroll
-                for (int e = 0; e < E; ++e) a[e] = Bfly<T, CLS>::pre_inverse(a[e], P);  // lazy accumulator -> inverse input
+                for (int e = 0; e < E; ++e) a[e] = chain_pre_inverse<T, CLS>(a[e], P);  // lazy accumulator -> inverse input
                 I::template pass<0>(a, lds, to, twi, imgi, P);  // canonical coefficients, layout RML
                 if constexpr (RML != IO_RM) {
                     F::wsync();
@@ -1083,7 +1087,7 @@ struct ExtOne {
             FB::template gather<RM0>(r, tb + ((size_t)j << LOGN), pdep<CM0>(tj), false);
 #pragma unroll
             for (int e = 0; e < E; ++e) r[e] = Bfly<T, CLS>::load_fix(r[e], P);
-            F::template pass<0, false, false, !Bfly<T, CLS>::FUSED_LAZY>(r, lds, tj, twf, nullptr, P);
+            F::template pass<0, false, false, mul_fwd_fin<T, CLS>()>(r, lds, tj, twf, nullptr, P);
             if constexpr (Bfly<T, CLS>::IS_FP) {
 #pragma unroll
                 for (int e = 0; e < E; ++e) r[e] = Bfly<T, CLS>::reduce(r[e], P);
@@ -1105,7 +1109,7 @@ struct ExtOne {
             uint32_t to = tid;
             asm volatile("" : "+v"(to));
 #pragma unroll
-            for (int e = 0; e < E; ++e) a[e] = Bfly<T, CLS>::pre_inverse(a[e], P);
+            for (int e = 0; e < E; ++e) a[e] = chain_pre_inverse<T, CLS>(a[e], P);
             I::template pass<0, false, false>(a, lds, to, twi, nullptr, P);  // canonical coefficients, layout RML
             T *dst = out + (((size_t)b * ostride + o.value) << LOGN);
             if (accumulate) {

@@ -296,6 +296,60 @@ def test_fused_mul_ntt_equals_three_calls(oracle, plans, oplans, bits, n, p):
             assert np.array_equal(got, oracle.negacyclic_convolution(n, p, a, b, bits))
 
 
+@pytest.mark.parametrize("bits,n,p", [(32, 256, 2127586817), (64, 256, 8762203435012018177)])
+def test_strict_class_keeps_the_reference_barrett_wrap(oracle, plans, oplans, bits, n, p):
+    """Primes of the strict class above 2^B / 3: the reference's Barrett product wraps for about 7e-4 of uniform operands on these two
+    (src/prime32.rs:398-401, src/prime64.rs:549-552; tests/test_oracle_properties.py::test_oracle_keeps_the_reference_barrett_wrap) and
+    its result is then NOT a b / n mod p.  Every device path -- the pointwise kernels, the fused product, the fused mul_accumulate
+    chain -- has to return the reference's words, not the exact ones (a Montgomery product in the fused kernels, tried in round 4,
+    returned the exact ones: found by tools/soak_random.py)."""
+    plan, ref = plans(bits, n, p), oplans(bits, n, p)
+    batch = 64
+    a = oracle.fill_uniform(batch * n, p, 3, bits)
+    bn = oracle.fill_uniform(batch * n, p, 4, bits)      # taken as NTT-domain words
+    # mul_assign_normalize: the wrap is there (the oracle differs from the exact product) and the device reproduces it
+    want = a.copy()
+    ref.mul_assign_normalize(want, bn)
+    n_inv = pow(n, -1, p)
+    assert any(int(want[i]) != int(a[i]) * int(bn[i]) * n_inv % p for i in range(batch * n))
+    d = to_dev(a)
+    plan.mul_assign_normalize_batch(d, to_dev(bn))
+    assert np.array_equal(to_host(d, plan.dtype), want)
+    # mul_accumulate
+    acc = oracle.fill_uniform(batch * n, p, 5, bits)
+    wacc = acc.copy()
+    ref.mul_accumulate(wacc, a, bn)
+    dacc = to_dev(acc)
+    plan.mul_accumulate_batch(dacc, to_dev(a), to_dev(bn))
+    assert np.array_equal(to_host(dacc, plan.dtype), wacc)
+    # fused product: lhs in the coefficient domain
+    wf = a.copy()
+    ref.fwd_batch(wf, 4)
+    exact_inputs = wf.copy()
+    ref.mul_assign_normalize(wf, bn)
+    assert any(int(wf[i]) != int(exact_inputs[i]) * int(bn[i]) * n_inv % p for i in range(batch * n))
+    ref.inv_batch(wf, 4)
+    d = to_dev(a)
+    plan.mul_ntt_batch(d, to_dev(bn))
+    assert np.array_equal(to_host(d, plan.dtype), wf)
+    # fused chain: J = 2 terms per element, O = 2 outputs
+    J, O, nb = 2, 2, batch // 2
+    key = bn[: J * O * n]
+    wout = np.zeros(nb * O * n, dtype=a.dtype)
+    ta = a.copy()
+    ref.fwd_batch(ta, 4)
+    for e in range(nb):
+        for o in range(O):
+            acc1 = np.zeros(n, dtype=a.dtype)
+            for j in range(J):
+                ref.mul_accumulate(acc1, ta[(e * J + j) * n:(e * J + j + 1) * n], np.ascontiguousarray(key[(j * O + o) * n:(j * O + o + 1) * n]))
+            ref.inv(acc1)
+            wout[(e * O + o) * n:(e * O + o + 1) * n] = acc1
+    dout = to_dev(np.zeros(nb * O * n, dtype=a.dtype))
+    plan.external_product_batch(dout, to_dev(a), to_dev(key), J, O, False)
+    assert np.array_equal(to_host(dout, plan.dtype), wout)
+
+
 P50, P51, P63, SOLINAS, PM64 = 1125899904679937, 2251799813554177, 9223372036853661697, 18446744069414584321, 18446744073707716609
 
 

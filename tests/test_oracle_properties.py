@@ -68,3 +68,63 @@ def test_native_round_trip_and_polymul(oracle, kind):
         prod = np.zeros_like(v)
         nat.negacyclic_polymul(prod, v, rhs)
         assert np.array_equal(prod, oracle.negacyclic_convolution(n, 0, v, rhs, wb))
+
+
+# primes of the strict class (2^(B-2) <= p < 2^(B-1)) above 2^B / 3 on which the wrap below happens for about 7e-4 of uniform products
+WRAP_PRIMES = [(32, 256, 2127586817), (64, 256, 8762203435012018177)]
+
+
+def _reference_barrett(bits, p, a, b):
+    """src/prime32.rs:398-401 / src/prime64.rs:549-552 on Python integers: the low B bits of d - c3 p."""
+    big_q = p.bit_length()
+    p_barrett = (1 << (big_q + bits - 1)) // p
+    d = a * b
+    c1 = (d >> (big_q - 1)) & ((1 << bits) - 1)
+    c3 = (c1 * p_barrett) >> bits
+    return (d - p * c3) & ((1 << bits) - 1), d - p * c3
+
+
+@pytest.mark.parametrize("bits,n,p", WRAP_PRIMES)
+def test_oracle_keeps_the_reference_barrett_wrap(oracle, bits, n, p):
+    """The reference's Barrett product keeps the low B bits of d - c3 p, a remainder estimate in [0, 3p): for p > 2^B / 3 it can
+    pass 2^B, and mul_assign_normalize / mul_accumulate are then off by 2^B mod p (src/prime32.rs:383-408, src/prime64.rs:534-584).
+    The oracle restates that arithmetic, so it reproduces the wrap: checked against the formula on Python integers, and against the
+    exact product to show that the wrap does happen on these inputs.  (Primes below 2^(B-2) -- 3p < 2^B -- cannot wrap.)"""
+    plan = oracle.Plan.try_new(n, p, bits)
+    dt = np.uint64 if bits == 64 else np.uint32
+    count = 64 * n
+    a, b = oracle.fill_uniform(count, p, 3, bits), oracle.fill_uniform(count, p, 4, bits)
+    got = a.copy()
+    for i in range(0, count, n):
+        plan.mul_assign_normalize(got[i:i + n], b[i:i + n])
+    acc0 = oracle.fill_uniform(count, p, 5, bits)
+    acc = acc0.copy()
+    for i in range(0, count, n):
+        plan.mul_accumulate(acc[i:i + n], a[i:i + n], b[i:i + n])
+    n_inv = pow(n, -1, p)
+    n_inv_shoup = (n_inv << bits) // p
+    mask, wraps = (1 << bits) - 1, 0
+    for i in range(count):
+        prod, full = _reference_barrett(bits, p, int(a[i]), int(b[i]))
+        wraps += full > mask
+        t = (prod * n_inv - ((prod * n_inv_shoup) >> bits) * p) & mask            # src/prime32.rs:403-406
+        assert int(got[i]) == min(t, (t - p) & mask)
+        prod = min(prod, (prod - p) & mask)                                       # src/prime64.rs:579-582
+        s = (prod + int(acc0[i])) & mask
+        assert int(acc[i]) == min(s, (s - p) & mask)
+        exact = int(a[i]) * int(b[i]) * n_inv % p
+        assert (int(got[i]) == exact) == (full <= mask)
+    assert wraps > 0
+
+
+def test_lazy_class_products_are_exact(oracle):
+    """below 2^(B-2) the remainder estimate stays under 3p < 2^B: the reference's products are the exact ones (what lets the GPU's
+    fused kernels use a Montgomery product for this class, csrc/ntt_arith.hpp mul_fused)."""
+    for bits, n, p in [(32, 256, 1062862849), (64, 256, 4611686018427322369)]:
+        plan = oracle.Plan.try_new(n, p, bits)
+        a, b = oracle.fill_uniform(16 * n, p, 3, bits), oracle.fill_uniform(16 * n, p, 4, bits)
+        got = a.copy()
+        for i in range(0, 16 * n, n):
+            plan.mul_assign_normalize(got[i:i + n], b[i:i + n])
+        n_inv = pow(n, -1, p)
+        assert all(int(got[i]) == int(a[i]) * int(b[i]) * n_inv % p for i in range(16 * n))
