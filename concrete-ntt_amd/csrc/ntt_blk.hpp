@@ -158,6 +158,10 @@ struct NttBlk {
         }
     }
 
+    // PREFETCH = false: every polynomial is read with ordinary loads where its transform begins -- for the shapes whose register
+    // need makes hipcc spill (32-bit words on doubles, the strict class's inverse at 32 coefficients per thread): harmless next to
+    // ordinary loads, fatal next to asynchronous ones (tests/test_async_load_guard.py)
+    template <bool PREFETCH = true>
     static __device__ __forceinline__ void run(T *__restrict__ data, const TwPair<T> *__restrict__ tw, const ModParams<T> &P,
                                                uint32_t nsub, T *lds) {
         using PF = Pf<LOAD_RM>;
@@ -172,11 +176,13 @@ struct NttBlk {
         // hipcc's vmcnt model with loads "in flight" at the loop header: it then waits for them INSIDE the loop, with
         // counts that on every later iteration drain the prefetch of the next polynomial right after it was issued
         // (no overlap of HBM and butterflies at all: measured 102 instead of 80 ns per polynomial at N = 16384).
-        if (tile < nsub) {
-            typename PF::V v0[PF::NVEC];
-            PF::issue(v0, (const T *)(data + ((size_t)tile << LOGN)), pdep<CML>(tid) * (uint32_t)sizeof(T));
-            PF::template wait<0>(v0);
-            PF::unpack(r, v0);
+        if constexpr (PREFETCH) {
+            if (tile < nsub) {
+                typename PF::V v0[PF::NVEC];
+                PF::issue(v0, (const T *)(data + ((size_t)tile << LOGN)), pdep<CML>(tid) * (uint32_t)sizeof(T));
+                PF::template wait<0>(v0);
+                PF::unpack(r, v0);
+            }
         }
         for (; tile < nsub; tile += gridDim.x) {
             // every address of the body is recomputed from an opaque copy of the thread index: left alone hipcc hoists
@@ -188,8 +194,11 @@ struct NttBlk {
             T *tbase = data + ((size_t)tile << LOGN);
             typename PF::V vn[PF::NVEC];
             auto prefetch = [&]() {
-                if (more) PF::issue(vn, (const T *)(data + ((size_t)tnext << LOGN)), pdep<CML>(tidv) * (uint32_t)sizeof(T));
+                if constexpr (PREFETCH) {
+                    if (more) PF::issue(vn, (const T *)(data + ((size_t)tnext << LOGN)), pdep<CML>(tidv) * (uint32_t)sizeof(T));
+                }
             };
+            if constexpr (!PREFETCH) B::template gather_tile<LOAD_RM>(r, (const T *)tbase, pdep<CML>(tidv) * (uint32_t)sizeof(T));
 #pragma unroll
             for (int j = 0; j < E; ++j) r[j] = Bfly<T, CLS>::load_fix(r[j], P);
             if constexpr (!INV) {
@@ -214,21 +223,23 @@ struct NttBlk {
                 for (int j = 0; j < E; ++j) r[j] = Bfly<T, CLS>::finish_inv(r[j], P);
             }
             B::template scatter_tile<STORE_RM>(r, tbase, pdep<CMS>(tidv) * (uint32_t)sizeof(T));
-            if (more) {
-                PF::template wait<NST>(vn);
-                PF::unpack(r, vn);
+            if constexpr (PREFETCH) {
+                if (more) {
+                    PF::template wait<NST>(vn);
+                    PF::unpack(r, vn);
+                }
             }
         }
     }
 };
 
-template <class T, int LOGN, bool INV, int CLS, int WPW, int TWC = 2>
+template <class T, int LOGN, bool INV, int CLS, int WPW, int TWC = 2, bool PREFETCH = true>
 __global__ __launch_bounds__((NttBlk<T, LOGN, INV, CLS>::WPB), WPW) void ntt_kernel_blk(T *__restrict__ data,
                                                                                      const TwPair<T> *__restrict__ tw,
                                                                                      const ModParams<T> P, uint32_t nsub) {
     using K = NttBlk<T, LOGN, INV, CLS, TWC>;
     __shared__ __attribute__((aligned(16))) T lds[K::B::LDS_WORDS_1];
-    K::run(data, tw, P, nsub, lds);
+    K::template run<PREFETCH>(data, tw, P, nsub, lds);
 }
 
 // -------------------------------------------------------------------------------------------------

@@ -37,12 +37,20 @@ template <class K> static constexpr bool wp_eligible() {
 // address registers: 112 VGPRs now, instantiated like the rest.)
 // Round 4: 32-bit words, N = 16384 / 32768 (2048-word blocks, 32 coefficients per thread).
 template <class T, int LOGN, bool INV, int CLS, bool SUB> static constexpr bool blk_eligible() {
-    // (the strict class's inverse and the double-precision class for p >= 2^31 want ~170 registers at 32 coefficients per thread --
-    // 20 ... 48 spilled next to the asynchronous prefetch: they stay on the plain one-polynomial-per-workgroup kernel)
     // Measured against the plain kernel on one box (profiles/r04_blk32_vs_plain.txt): n = 16384 +10 % / +6 % (30-bit fwd / inv), +14 % (31-bit
     // fwd); n = 32768 +12 % / +32 %, +28 %; n = 8192 -1 ... -4 % -- four 512-thread workgroups per CU already overlap there: not used.
-    if (sizeof(T) == 4) return !SUB && LOGN >= 14 && LOGN <= 15 && (CLS == CLS_LAZY || (CLS == CLS_STRICT && !INV));
+    // The strict class's inverse and the double-precision class for p >= 2^31 want ~170 registers at 32 coefficients per thread and spill
+    // 20 ... 48 of them next to the asynchronous prefetch, which is fatal (tests/test_async_load_guard.py); WITHOUT the prefetch (ordinary
+    // loads where the transform begins, NttBlk::run<false>: 102 ... 118 VGPRs, no spills) the walk still wins where three or four workgroups per
+    // CU do not already overlap: p >= 2^31 n = 32768 141.0 -> 102.6 / 127.7 -> 104.2 ns (23.3 -> 31.9 % / 25.7 -> 31.5 % of the roofline), n = 16384
+    // 56.0 -> 49.4 / 57.4 -> 48.1 ns (29.2 -> 33.2 % / 28.5 -> 34.1 %), n = 8192 +6 % / +1 % slower (not used); 31-bit inverse n = 32768 118.0 -> 97.8 ns
+    // (27.8 -> 33.5 %), n = 16384 +-4 % over two boxes (not used).  profiles/r04_blk32_noprefetch_ab.txt
+    if (sizeof(T) == 4) return !SUB && LOGN >= 14 && LOGN <= 15 && (CLS == CLS_LAZY || CLS == CLS_FPW || (CLS == CLS_STRICT && (!INV || LOGN == 15)));
     return sizeof(T) == 8 && !SUB && LOGN >= 12 && LOGN <= 14 && CLS != CLS_GENERIC;
+}
+// the shapes that spill run the walk without the asynchronous prefetch
+template <class T, bool INV, int CLS> static constexpr bool blk_prefetch() {
+    return !(sizeof(T) == 4 && (CLS == CLS_FPW || (CLS == CLS_STRICT && INV)));
 }
 // (double-buffered: 2 * TWC pairs are in flight; the forward kernels hold the prefetch across these passes, the inverse ones
 // issue it behind them)
@@ -68,8 +76,8 @@ static hipError_t launch_one(T *data, const TwPair<T> *tw, const ModParams<T> &P
             constexpr int BPC = BY_LDS < BY_WAVES ? BY_LDS : BY_WAVES;
             uint32_t grid = (uint32_t)num_cus() * BPC;
             if (grid > nsub) grid = nsub;
-            hipLaunchKernelGGL((ntt_kernel_blk<T, LOGN, INV, CLS, 4, (sizeof(T) == 4 ? 2 : blk_twc(LOGN, INV, CLS))>), dim3(grid),
-                               dim3(W::WPB), 0, stream, data, tw, P, nsub);
+            hipLaunchKernelGGL((ntt_kernel_blk<T, LOGN, INV, CLS, 4, (sizeof(T) == 4 ? 2 : blk_twc(LOGN, INV, CLS)), blk_prefetch<T, INV, CLS>()>),
+                               dim3(grid), dim3(W::WPB), 0, stream, data, tw, P, nsub);
             return hipGetLastError();
         }
     }

@@ -1,6 +1,7 @@
 // One launch of the fused product kernel (MulWp) for a fixed (T, LOGN, CLS) and its workgroup shape.  Shared by the
 // integer-class instantiation units (ntt_mul_inst.inc) and the CLS_FP unit (ntt_inst_u64_fp.hip).
 #pragma once
+#include <cstdlib>
 #include "ntt_blk.hpp"
 #include "ntt_kernel.hpp"
 #include "ntt_launch.hpp"
@@ -67,6 +68,33 @@ static hipError_t mul_blk_one(T *lhs, const T *rhs, const TwPair<T> *twf, const 
     if (grid > nsub) grid = nsub;
     hipLaunchKernelGGL((mul_kernel_blk<T, LOGN, CLS, SH::WPW, SH::TWC, SH::PREFETCH>), dim3(grid), dim3(K::WPB), 0, stream, lhs, rhs,
                        twf, twi, P, nsub);
+    return hipGetLastError();
+}
+
+// 32-bit words, N = 16384 / 32768 on the same walk (2048-word blocks, 32 coefficients per thread; two 512-thread / one 1024-thread workgroup per CU)
+// where it beats the one-polynomial-per-workgroup kernel (MulOne); ordinary loads except for the one shape with the registers to spare (an
+// asynchronous load must not meet a spilled register).  Same box, ns per product, walk / MulOne (tools/mul_bench.py, CNTT_MUL32_BLK=0 for the latter):
+//   30-bit  n = 16384  71.3 / 73.8 (-3.4 %, with the prefetch; -1.7 % without)   n = 32768  156.5 / 173.5 (-9.8 %)
+//   31-bit  n = 16384  81.5 / 75.4 (+8.1 %: not used)                             n = 32768  176.5 / 195.7 (-9.8 %)
+//   p>=2^31 n = 16384  95.2 / 101.4 (-6.2 %)                                      n = 32768  216.2 / 204.1 (+5.9 %, 17 spilled registers: not used)
+constexpr bool mul32_blk_wins(int logn, int cls) {
+    return (cls == CLS_LAZY && (logn == 14 || logn == 15)) || (cls == CLS_STRICT && logn == 15) || (cls == CLS_FPW && logn == 14);
+}
+static bool mul32_blk_enabled() {
+    static const bool on = [] {
+        const char *e = std::getenv("CNTT_MUL32_BLK");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+template <class T, int LOGN, int CLS>
+static hipError_t mul32_blk_one(T *lhs, const T *rhs, const TwPair<T> *twf, const TwPair<T> *twi, const ModParams<T> &P,
+                                uint32_t nsub, hipStream_t stream) {
+    constexpr bool PF = LOGN == 14 && CLS == CLS_LAZY;   // 112 VGPRs with the prefetch in flight, no spills
+    using K = MulBlk<T, LOGN, CLS, 2, PF>;
+    uint32_t grid = (uint32_t)mul_num_cus() * (LOGN == 14 ? 2 : 1);
+    if (grid > nsub) grid = nsub;
+    hipLaunchKernelGGL((mul_kernel_blk<T, LOGN, CLS, 4, 2, PF>), dim3(grid), dim3(K::WPB), 0, stream, lhs, rhs, twf, twi, P, nsub);
     return hipGetLastError();
 }
 

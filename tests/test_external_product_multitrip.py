@@ -84,6 +84,10 @@ def _round_blk(cus, n, O):   # ext_kernel_blk: one element per workgroup, PER_CU
     return cus * ((3 if O <= 2 else 2) if n == 4096 else 1)
 
 
+def _round_blk32(cus, n):    # ext_kernel_blk on 32-bit words (one output): two 512-thread workgroups per CU at n = 16384, one at 32768
+    return cus * (2 if n == 16384 else 1)
+
+
 CASES = [
     # bits, n, p, J, O, kernel
     (64, 1024, P62, 2, 1, "wp"),
@@ -107,6 +111,10 @@ CASES = [
     (64, 16384, FP51, 2, 1, "blk"),
     (64, 16384, P62, 2, 4, "blk"),     # four outputs at this size: TWO launches of the two-output kernel over the same batch
     (64, 16384, SOLINAS, 2, 3, "blk"),
+    # 32-bit words on the wave-block walk (round 4: one output; 30-bit n = 16384, p >= 2^31 n = 16384 / 32768)
+    (32, 16384, P30, 2, 1, "blk32"),
+    (32, 16384, P32, 2, 1, "blk32"),
+    (32, 32768, P32, 2, 1, "blk32"),
 ]
 
 
@@ -125,7 +133,7 @@ def run_chain_case(oracle, bits, n, p, J, O, kernel, accumulate, idx):
     plan, oplan = mod.Plan.try_new(n, p), oracle.Plan.try_new(n, p, bits)
     assert plan is not None and oplan is not None
     cus = _cus()
-    per_round = _round_wp(cus) if kernel == "wp" else _round_blk(cus, n, O)
+    per_round = _round_wp(cus) if kernel == "wp" else _round_blk32(cus, n) if kernel == "blk32" else _round_blk(cus, n, O)
     batch = 2 * per_round + per_round // 3 + 5   # a third, partial trip with a ragged last tile
     terms = oracle.fill_uniform(batch * J * n, p, 1000 + idx, bits)
     key = oracle.fill_uniform(J * O * n, p, 2000 + idx, bits)

@@ -138,6 +138,31 @@ def test_u32_every_size_vs_oracle(oracle, plans, oplans, logn):
     _batch_case(oracle, plans, oplans, 32, n, 1062862849, batch, 2000 + logn)
 
 
+@pytest.mark.parametrize("n,p", [(16384, 1062862849), (32768, 1062862849), (16384, 2147352577), (32768, 2147352577),
+                                 (16384, 4293918721), (32768, 4293918721)])
+def test_u32_wave_block_walk_takes_several_trips(oracle, plans, oplans, n, p):
+    """32-bit words at n = 16384 / 32768 on the persistent wave-block walk (ntt_kernel_blk<u32>: two 512-thread / one 1024-thread
+    workgroup per CU; round 4: p >= 2^31 and the 31-bit class's inverse at n = 32768 too, with ordinary loads instead of the asynchronous
+    prefetch): two rounds of the resident grid plus a ragged third, every polynomial against the oracle, both directions."""
+    import torch
+    plan, ref = plans(32, n, p), oplans(32, n, p)
+    per_round = torch.cuda.get_device_properties(0).multi_processor_count * (2 if n == 16384 else 1)
+    batch = 2 * per_round + per_round // 3 + 3
+    a = oracle.fill_uniform(batch * n, p, 4242 + n, 32)
+    want = a.copy()
+    ref.fwd_batch(want, 8)
+    d = to_dev(a)
+    plan.fwd_batch(d)
+    got = to_host(d, plan.dtype)
+    bad = np.nonzero((got != want).reshape(batch, n).any(axis=1))[0]
+    assert bad.size == 0, ("fwd: polynomials differing from the oracle", bad[:8], batch, per_round)
+    ref.inv_batch(want, 8)
+    plan.inv_batch(d)
+    got = to_host(d, plan.dtype)
+    bad = np.nonzero((got != want).reshape(batch, n).any(axis=1))[0]
+    assert bad.size == 0, ("inv: polynomials differing from the oracle", bad[:8], batch, per_round)
+
+
 @pytest.mark.parametrize("p", U64_PRIMES)
 @pytest.mark.parametrize("n", [16, 256, 1024, 4096])
 def test_u64_every_class_vs_oracle(oracle, plans, oplans, p, n):
@@ -366,6 +391,27 @@ def test_fused_mul_ntt_large_sizes(oracle, plans, oplans, n, p):
     for batch in (1, 5, 1100 if n == 4096 else 530 if n == 8192 else 270 if n == 16384 else 260):
         a = oracle.fill_uniform(batch * n, p, 131 + batch, 64)
         b = oracle.fill_uniform(batch * n, p, 197 + batch, 64)
+        want, bn = a.copy(), b.copy()
+        ref.fwd_batch(bn, 8)
+        ref.fwd_batch(want, 8)
+        ref.mul_assign_normalize(want, bn)
+        ref.inv_batch(want, 8)
+        da = to_dev(a)
+        plan.mul_ntt_batch(da, to_dev(bn))
+        got = to_host(da, plan.dtype)
+        bad = np.nonzero(got != want)[0]
+        assert bad.size == 0, "n=%d p=%d batch=%d: %d mismatches, first at %d" % (n, p, batch, bad.size, bad[0])
+
+
+@pytest.mark.parametrize("n,p", [(16384, 1062862849), (32768, 1062862849), (32768, 2147352577), (16384, 4293918721)])
+def test_fused_mul_ntt_large_sizes_u32(oracle, plans, oplans, n, p):
+    """32-bit words on the wave-block walk (round 4: mul_kernel_blk<u32>, 2048-word blocks; the 30-bit class at n = 16384 with the
+    asynchronous prefetch of the next polynomial, the others with ordinary loads): more polynomials than two rounds of the resident grid
+    (two 512-thread / one 1024-thread workgroup per CU) and a ragged tail, against fwd; mul_assign_normalize; inv of the oracle."""
+    plan, ref = plans(32, n, p), oplans(32, n, p)
+    for batch in (3, 1100 if n == 16384 else 560):
+        a = oracle.fill_uniform(batch * n, p, 131 + batch, 32)
+        b = oracle.fill_uniform(batch * n, p, 197 + batch, 32)
         want, bn = a.copy(), b.copy()
         ref.fwd_batch(bn, 8)
         ref.fwd_batch(want, 8)
