@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Extended run of the seeded random GPU parity sweeps (tests/test_gpu_random.py) over many more seeds than the
 test suite uses: prime plans, native polymul plans, product plans.  Prints the failing seeds, if any.
-    python tools/soak_random.py [extra_seeds_per_family] [plans|native|product|chain]
+    python tools/soak_random.py [extra_seeds_per_family] [plans|native|product|chain|wrap]
 `chain`: the fused mul_accumulate chain kernels with batches of more than two rounds of their persistent grids (random
 primes of every class, random sizes / terms / outputs; tests/test_external_product_multitrip.py::run_chain_case)."""
 import os
@@ -52,5 +52,34 @@ if only in (None, "chain"):
             print("FAIL chain", seed, (bits, n, p, J, O), repr(e)[:300], flush=True)
         print("chain seed", seed, (bits, n, p, J, O), flush=True)
     print("chain done", flush=True)
+if only in (None, "wrap"):
+    # strict-class primes above 2^B / 3, where the reference's Barrett product can wrap: pointwise kernels, fused product, fused
+    # chain against the oracle
+    import random
+    import test_gpu_parity as gp
+    from concrete_ntt_amd import prime32, prime64
+    for seed in range(extra if only == "wrap" else max(extra // 10, 1)):
+        rng = random.Random(9000 + seed)
+        bits = 64 if seed % 2 == 0 else 32
+        n = 1 << rng.randint(4 if bits == 64 else 5, 12)
+        hi = rng.randint((1 << bits) // 3, (1 << (bits - 1)) - 1)
+        p = oracle.largest_prime_in_arithmetic_progression64(2 * n, 1, 0, hi)
+        if p is None or p <= (1 << bits) // 3:
+            continue
+        plan, ref = (prime64 if bits == 64 else prime32).Plan.try_new(n, p), oracle.Plan.try_new(n, p, bits)
+        if plan is None:
+            continue
+        try:
+            nskip = gp.run_wrap_case(oracle, plan, ref, bits, n, p, max(2, 16384 // n) & ~1, False, seed)
+            if nskip:
+                print("wrap seed", seed, (bits, n, p), "chain outputs left out (non-canonical reference accumulators):", nskip, flush=True)
+        except BaseException as e:
+            if type(e).__name__ == "Skipped":
+                continue
+            bad += 1
+            print("FAIL wrap", seed, (bits, n, p), repr(e)[:300], flush=True)
+        if seed % 20 == 0:
+            print("wrap seed", seed, (bits, n, p), flush=True)
+    print("wrap done", flush=True)
 print("soak done, failures:", bad)
 sys.exit(1 if bad else 0)
