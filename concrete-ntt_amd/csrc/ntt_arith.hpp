@@ -6,8 +6,11 @@
 // Three arithmetic classes, chosen per plan at creation from the modulus:
 //   CLS_LAZY    p < 2^(B-2): Harvey lazy butterflies, values in [0,4p) (fwd) / [0,2p) (inv), as
 //               src/prime64/less_than_62bit.rs:117-154,271-310 and src/prime32/less_than_30bit.rs
-//   CLS_STRICT  p < 2^(B-1): values in [0,2p), as src/prime64/less_than_63bit.rs:117-154,214-232 (the sums that may
-//               pass 2^B are corrected with their carry)
+//   CLS_STRICT  p < 2^(B-1): the butterflies of src/prime64/less_than_63bit.rs:117-154,214-232 (src/prime32/less_than_31bit.rs)
+//               operation for operation -- words below p, every sum and Shoup product brought back by ONE min(x, x - p).
+//               (Rounds 1-3 kept this class lazy in [0, 2p) with carry-aware corrections: same results on canonical inputs,
+//               but the reference's own mul_accumulate can hand its inverse transform a word in [p, 2^B - p) for these
+//               primes -- DESIGN 4 -- and only the same instruction sequence returns the same words then.)
 //   CLS_GENERIC any p (used for p >= 2^(B-1), incl. Solinas): canonical values, Montgomery
 //               products against twiddles stored in Montgomery form.  The reference does exact
 //               `%`-products there (src/prime64/generic_solinas.rs:42-128): same values.
@@ -143,6 +146,24 @@ template <class T> __device__ __forceinline__ T umin(T a, T b) { return a < b ? 
 // x in [0, 2m) -> [0, m)
 template <class T> __device__ __forceinline__ T csub(T x, T m) { return umin<T>(x, x - m); }
 
+// min(x, x - p) for the strict class's butterflies: the borrow of the subtraction is the select condition (four instructions for 64 bits;
+// hipcc recomputes it with a 64-bit compare and copies the high half of p into a VGPR for v_subb: six), p in scalar registers
+template <class T> __device__ __forceinline__ T csub_p(T x, T p) {
+    if constexpr (sizeof(T) == 8) {
+        const uint32_t x0 = (uint32_t)x, x1 = (uint32_t)(x >> 32), p0 = (uint32_t)p, p1 = (uint32_t)(p >> 32);
+        uint32_t r0, r1;
+        // (the high half of p in a VGPR: the carry-in already takes v_subb's one scalar operand)
+        asm("v_subrev_co_u32 %0, vcc, %4, %2\n\t"
+            "v_subb_co_u32 %1, vcc, %3, %5, vcc\n\t"
+            "v_cndmask_b32 %0, %0, %2, vcc\n\t"
+            "v_cndmask_b32 %1, %1, %3, vcc"
+            : "=&v"(r0), "=&v"(r1) : "v"(x0), "v"(x1), "s"(p0), "v"(p1) : "vcc");
+        return ((uint64_t)r1 << 32) | r0;
+    } else {
+        return umin<T>(x, x - p);
+    }
+}
+
 // x in [0, 4p) -> [0, 2p): select (-2p or 0) and add -- v_cmp + 2 v_cndmask + v_lshl_add_u64 for 64 bits
 template <class T> __device__ __forceinline__ T csub_two_p(T x, T two_p, T neg_two_p) {
     if constexpr (sizeof(T) == 8) {
@@ -222,13 +243,11 @@ template <class T, int CLS> struct Bfly {
                 x = x + t;
             }
         } else if constexpr (CLS == CLS_STRICT) {
-            // x, t in [0, 2p), 2p < 2^B <= 4p: the sum may pass 2^B -- one carry-aware conditional subtraction of 2p on
-            // each output instead of bringing x and t below p first
-            const T t = shoup_mul<T, UNI>(y, w, ws, P.neg_p);
-            const T s = x + t;
-            const T d = x - t;
-            y = d + (x < t ? P.two_p : (T)0);
-            x = s + (((s < x) | (s >= P.two_p)) ? P.neg_two_p : (T)0);
+            // fwd_butterfly_scalar (less_than_63bit.rs:117-133): z0 = min(z0, z0 - p); t = min(t, t - p); (z0 + t, z0 - t + p), both in [0, 2p)
+            const T z0 = csub_p<T>(x, P.p);
+            const T t = csub_p<T>(shoup_mul<T, UNI>(y, w, ws, P.neg_p), P.p);
+            x = z0 + t;
+            y = (z0 - t) + P.p;
         } else {
             const T t = mont_mul(y, w, P.p, P.pinv_neg);
             const T x0 = x;
@@ -248,10 +267,10 @@ template <class T, int CLS> struct Bfly {
             else x = csub_two_p<T>(x + y, P.two_p, P.neg_two_p);
             y = shoup_mul<T, UNI>(d, w, ws, P.neg_p);
         } else if constexpr (CLS == CLS_STRICT) {
-            const T s = x + y;
-            const T d = (x - y) + (x < y ? P.two_p : (T)0);
-            x = s + (((s < x) | (s >= P.two_p)) ? P.neg_two_p : (T)0);
-            y = shoup_mul<T, UNI>(d, w, ws, P.neg_p);   // [0, 2p)
+            // inv_butterfly_scalar (less_than_63bit.rs:214-232): words below p in, words below p out; wrapping sums as there
+            const T t = (x - y) + P.p;
+            x = csub_p<T>(x + y, P.p);
+            y = csub_p<T>(shoup_mul<T, UNI>(t, w, ws, P.neg_p), P.p);
         } else {
             const T x0 = x;
             x = add_mod<T>(x0, y, P.p);
@@ -266,7 +285,7 @@ template <class T, int CLS> struct Bfly {
         if constexpr (CLS == CLS_LAZY) {
             x = shoup_mul<T, true>(x, P.n_inv, P.n_inv_shoup, P.neg_p);  // [0, 2p)
         } else if constexpr (CLS == CLS_STRICT) {
-            x = shoup_mul<T, true>(x, P.n_inv, P.n_inv_shoup, P.neg_p);  // [0, 2p)
+            x = csub<T>(shoup_mul<T, true>(x, P.n_inv, P.n_inv_shoup, P.neg_p), P.p);  // (finish_inv is the identity for this class)
         } else {
             x = mont_mul(x, P.n_inv, P.p, P.pinv_neg);  // n_inv field = N^-1 R^2: x / R * (N^-1 R^2) / R ... see mul_for_inv
         }
@@ -280,13 +299,13 @@ template <class T, int CLS> struct Bfly {
     static __device__ __forceinline__ T pre_inverse(T v, const ModParams<T> &) { return v; }
     // bring a value left by the last stage into [0, p)
     static __device__ __forceinline__ T finish_fwd(T v, const ModParams<T> &P) {
-        if constexpr (CLS == CLS_LAZY) return csub<T>(csub_two_p<T>(v, P.two_p, P.neg_two_p), P.p);
-        if constexpr (CLS == CLS_STRICT) return csub<T>(v, P.p);
+        if constexpr (CLS == CLS_LAZY) return csub<T>(csub_two_p<T>(v, P.two_p, P.neg_two_p), P.p);   // (csub_p here: +-2 %, not kept)
+        if constexpr (CLS == CLS_STRICT) return csub_p<T>(v, P.p);
         return v;
     }
     static __device__ __forceinline__ T finish_inv(T v, const ModParams<T> &P) {
-        if constexpr (CLS == CLS_LAZY || CLS == CLS_STRICT) return csub<T>(v, P.p);
-        return v;
+        if constexpr (CLS == CLS_LAZY) return csub<T>(v, P.p);
+        return v;   // (strict class: the reference's inverse butterflies leave their outputs as they are -- so does this one)
     }
 };
 
@@ -657,7 +676,9 @@ template <class T, int CLS> __device__ __forceinline__ T mul_for_inv(T a, T b, c
     } else if constexpr (CLS == CLS_GENERIC) {
         return mont_mul(a, b, P.p, P.pinv_neg);
     } else if constexpr (CLS == CLS_STRICT) {
-        return csub<T>(barrett_mul_lazy<T>(a, b, P), P.p);
+        // the low B bits of a remainder estimate in [0, 3p) (barrett_mul_lazy, as the reference: whatever that word is, its residue is what the
+        // reference multiplies by 1/N): two conditional subtractions make it canonical, which this class's inverse butterflies assume
+        return csub<T>(csub<T>(barrett_mul_lazy<T>(a, b, P), P.p), P.p);
     } else {
         return barrett_mul_lazy<T>(a, b, P);
     }

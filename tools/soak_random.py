@@ -72,7 +72,7 @@ if only in (None, "wrap"):
         try:
             nskip = gp.run_wrap_case(oracle, plan, ref, bits, n, p, max(2, 16384 // n) & ~1, False, seed)
             if nskip:
-                print("wrap seed", seed, (bits, n, p), "chain outputs left out (non-canonical reference accumulators):", nskip, flush=True)
+                print("wrap seed", seed, (bits, n, p), "chain outputs whose reference accumulators left the canonical range (compared like the rest):", nskip, flush=True)
         except BaseException as e:
             if type(e).__name__ == "Skipped":
                 continue
