@@ -146,15 +146,18 @@ template <class T> __device__ __forceinline__ T umin(T a, T b) { return a < b ? 
 // x in [0, 2m) -> [0, m)
 template <class T> __device__ __forceinline__ T csub(T x, T m) { return umin<T>(x, x - m); }
 
-// min(x, x - p) for the strict class's butterflies: the borrow of the subtraction is the select condition (four instructions for 64 bits;
-// hipcc recomputes it with a 64-bit compare and copies the high half of p into a VGPR for v_subb: six), p in scalar registers
+// min(x, x - p) for the strict class's butterflies: the borrow of the subtraction is the select condition (four instructions and two
+// s_nop for 64 bits; hipcc recomputes the condition with a 64-bit compare: five and the same two s_nop), p in scalar registers
 template <class T> __device__ __forceinline__ T csub_p(T x, T p) {
     if constexpr (sizeof(T) == 8) {
         const uint32_t x0 = (uint32_t)x, x1 = (uint32_t)(x >> 32), p0 = (uint32_t)p, p1 = (uint32_t)(p >> 32);
         uint32_t r0, r1;
-        // (the high half of p in a VGPR: the carry-in already takes v_subb's one scalar operand)
+        // (the high half of p in a VGPR: the carry-in already takes v_subb's one scalar operand.  gfx950 has no interlock between a VALU
+        // write of VCC and a VALU read of it -- two wait states, which hipcc pads in its own code and nobody pads inside an asm string)
         asm("v_subrev_co_u32 %0, vcc, %4, %2\n\t"
+            "s_nop 1\n\t"
             "v_subb_co_u32 %1, vcc, %3, %5, vcc\n\t"
+            "s_nop 1\n\t"
             "v_cndmask_b32 %0, %0, %2, vcc\n\t"
             "v_cndmask_b32 %1, %1, %3, vcc"
             : "=&v"(r0), "=&v"(r1) : "v"(x0), "v"(x1), "s"(p0), "v"(p1) : "vcc");
