@@ -53,8 +53,10 @@ template <class T, bool INV, int CLS> static constexpr bool blk_prefetch() {
     return !(sizeof(T) == 4 && (CLS == CLS_FPW || (CLS == CLS_STRICT && INV)));
 }
 // (double-buffered: 2 * TWC pairs are in flight; the forward kernels hold the prefetch across these passes, the inverse ones
-// issue it behind them)
-static constexpr int blk_twc(int logn, bool inv, int cls) { return (inv && cls != CLS_STRICT) ? 2 : 1; }
+// issue it behind them.  Until late round 4 the forward kernels took one pair at a time -- two fit since the padded exchange layout freed
+// the swizzle's address registers (108 ... 118 VGPRs, no spills): 62-bit N = 16384 0.348 -> 0.362 of the roofline (C4's forward pass), N = 4096
+// -2.4 %, 63-bit -2.4 ... -4.5 %, 2^64 - c -0.4 ... -2.7 %, the double-precision classes +-1 %; same-box A/B, profiles/r04_blk_twc_ab.txt)
+static constexpr int blk_twc(int logn, bool inv, int cls) { return (inv && cls == CLS_STRICT) ? 1 : 2; }
 static bool blk_enabled() {  // CNTT_DISABLE_BLK=1: one polynomial per workgroup, no persistent walk (A/B runs)
     static const bool on = [] {
         const char *e = std::getenv("CNTT_DISABLE_BLK");

@@ -57,7 +57,7 @@ template <int LOGN, int CLS> struct MulBlkShape {
     static constexpr int WPW = 4;
     static constexpr int PER_CU = LOGN == 12 ? 4 : LOGN == 13 ? 2 : 1;
     static constexpr bool PREFETCH = true;
-    static constexpr int TWC = 1;
+    static constexpr int TWC = 2;   // (one pair until late round 4: 110 ... 118 VGPRs with two, no spills; -1 ... -3.6 % in ten of twelve shapes, +1 % in two)
 };
 template <class T, int LOGN, int CLS>
 static hipError_t mul_blk_one(T *lhs, const T *rhs, const TwPair<T> *twf, const TwPair<T> *twi, const ModParams<T> &P,
