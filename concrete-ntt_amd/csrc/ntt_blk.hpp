@@ -668,14 +668,14 @@ struct ExtBlk {
     }
 };
 
-template <class T, int LOGN, int CLS, int WPW, int NOUT>
+template <class T, int LOGN, int CLS, int WPW, int NOUT, int TWC = 1>
 __global__ __launch_bounds__((ExtBlk<T, LOGN, CLS, NOUT>::WPB), WPW) void ext_kernel_blk(T *__restrict__ out, const T *__restrict__ terms,
                                                                                    const T *__restrict__ key_ntt,
                                                                                    const TwPair<T> *__restrict__ twf,
                                                                                    const TwPair<T> *__restrict__ twi, const ModParams<T> P,
                                                                                    uint32_t nb, uint32_t nterms, uint32_t accumulate,
                                                                                    uint32_t ostride) {
-    using K = ExtBlk<T, LOGN, CLS, NOUT>;
+    using K = ExtBlk<T, LOGN, CLS, NOUT, TWC>;
     __shared__ __attribute__((aligned(16))) T lds[K::FB::LDS_WORDS_1];
     K::run(out, terms, key_ntt, twf, twi, P, nb, nterms, accumulate != 0, ostride, lds);
 }

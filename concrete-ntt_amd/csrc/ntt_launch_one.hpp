@@ -56,7 +56,8 @@ template <class T, bool INV, int CLS> static constexpr bool blk_prefetch() {
 // issue it behind them.  Until late round 4 the forward kernels took one pair at a time -- two fit since the padded exchange layout freed
 // the swizzle's address registers (108 ... 118 VGPRs, no spills): 62-bit N = 16384 0.348 -> 0.362 of the roofline (C4's forward pass), N = 4096
 // -2.4 %, 63-bit -2.4 ... -4.5 %, 2^64 - c -0.4 ... -2.7 %, the double-precision classes +-1 %; same-box A/B, profiles/r04_blk_twc_ab.txt)
-static constexpr int blk_twc(int logn, bool inv, int cls) { return (inv && cls == CLS_STRICT) ? 1 : 2; }
+// (the strict class's inverse too: 106 ... 108 VGPRs on the reference-form butterflies, -1.1 ... -1.9 %)
+static constexpr int blk_twc(int logn, bool inv, int cls) { return 2; }
 static bool blk_enabled() {  // CNTT_DISABLE_BLK=1: one polynomial per workgroup, no persistent walk (A/B runs)
     static const bool on = [] {
         const char *e = std::getenv("CNTT_DISABLE_BLK");
