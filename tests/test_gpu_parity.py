@@ -331,6 +331,34 @@ def test_strict_class_keeps_the_reference_barrett_wrap(oracle, plans, oplans, bi
     run_wrap_case(oracle, plans(bits, n, p), oplans(bits, n, p), bits, n, p, 64, True)
 
 
+@pytest.mark.parametrize("bits,p", [(64, 8762203435012018177), (64, 9223372036853661697), (32, 2127586817), (32, 2147352577),
+                                    (32, 1944588929)])
+def test_strict_class_transforms_mirror_the_reference_on_any_word(oracle, bits, p):
+    """The strict class (31- / 63-bit primes) runs the reference's butterflies operation for operation (src/prime64/less_than_63bit.rs:117-154,
+    214-232, src/prime32/less_than_31bit.rs; csrc/ntt_arith.hpp Bfly<T, CLS_STRICT>), because the reference's own mul_accumulate can hand `inv`
+    a word above p for these primes.  Consequence, checked here: fwd and inv return the ORACLE'S words for ANY input word -- below 2p
+    or anywhere in the B-bit range, far outside the API's contract -- on every kernel family (single pass, persistent walk, wave blocks, one
+    polynomial per workgroup).  (The lazy classes are specified on canonical inputs only.)"""
+    from concrete_ntt_amd import prime32, prime64
+    mod = prime64 if bits == 64 else prime32
+    seen = 0
+    for n in ((16, 32, 256, 1024, 4096, 16384) if bits == 64 else (32, 256, 1024, 4096, 16384, 32768)):
+        plan, ref = mod.Plan.try_new(n, p), oracle.Plan.try_new(n, p, bits)
+        assert (plan is None) == (ref is None)
+        if plan is None:
+            continue
+        for bound in (2 * p, 0):      # 0: raw B-bit words
+            a = oracle.fill_uniform(8 * n, bound if bound < (1 << bits) else 0, 77 + n, bits)
+            for name in ("fwd", "inv"):
+                want = a.copy()
+                getattr(ref, name + "_batch")(want, 4)
+                d = to_dev(a)
+                getattr(plan, name + "_batch")(d)
+                assert np.array_equal(to_host(d, plan.dtype), want), (name, bits, n, p, bound)
+                seen += 1
+    assert seen >= 4
+
+
 def run_wrap_case(oracle, plan, ref, bits, n, p, batch, require_wrap, seed=0):
     """(also driven with random strict-class primes above 2^B / 3 by tools/soak_random.py wrap)"""
     a = oracle.fill_uniform(batch * n, p, 3 + seed, bits)
