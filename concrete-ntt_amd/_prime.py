@@ -20,6 +20,8 @@ class PrimePlan:
     def check_canonical(self, buf):
         """Raise Panic if a host array holds a word >= modulus (the transforms do not check: see the class docstring)."""
         a = np.asarray(buf)
+        if a.dtype.kind == "i":   # device tensors travel as int64 / int32: compare the words as the unsigned words they are
+            a = a.view(np.dtype("u%d" % a.dtype.itemsize))
         if a.size and int(a.max()) >= self.modulus():
             raise Panic("coefficient %d >= modulus %d: outside the transforms' input contract" % (int(a.max()), self.modulus()))
 

@@ -259,15 +259,14 @@ template <class T, int CLS> struct Bfly {
         }
     }
     // inverse (Gentleman-Sande): (x, y) <- (x + y, (x - y) w)
-    // FIRST: the first stage of a stand-alone inverse transform -- x and y are memory words, canonical by the API's contract, so
-    // x + y < 2p already and the lazy class's conditional subtraction is left out (round 4; the fused kernels' inverse halves start
-    // from products in [0, 2p) and keep it)
+    // Every stage reduces its sum, the first one included (less_than_62bit.rs:282-283): the reference's own mul_accumulate can leave a
+    // word in [p, 2p) for lazy primes just above a power of two (its Barrett estimate reaches 2p there), and fwd -> mul_accumulate ->
+    // inv must still come out right.  (Round 4 skipped the first stage's reduction for "canonical" memory words: ADVICE round 4.)
     template <bool UNI = false, bool FIRST = false>
     static __device__ __forceinline__ void inv(T &x, T &y, T w, T ws, const ModParams<T> &P) {
         if constexpr (CLS == CLS_LAZY) {
             const T d = (x + P.two_p) - y;
-            if constexpr (FIRST) x = x + y;
-            else x = csub_two_p<T>(x + y, P.two_p, P.neg_two_p);
+            x = csub_two_p<T>(x + y, P.two_p, P.neg_two_p);
             y = shoup_mul<T, UNI>(d, w, ws, P.neg_p);
         } else if constexpr (CLS == CLS_STRICT) {
             // inv_butterfly_scalar (less_than_63bit.rs:214-232): words below p in, words below p out; wrapping sums as there
@@ -356,7 +355,7 @@ template <int CLS> struct BoxOps {
         const uint32_t x = (uint32_t)X, y = (uint32_t)Y;
         const uint32_t d = (x + P.two_p) - y;
         const uint32_t s = x + y;
-        X = box32(FIRST ? s : umin<uint32_t>(s, s - P.two_p));   // (FIRST: see Bfly::inv)
+        X = box32(umin<uint32_t>(s, s - P.two_p));   // (every stage, the first included: see Bfly::inv)
         const uint32_t q = __umulhi(d, ws);
         Y = mad_box<true>(q, P.neg_p, mul_box<UNI>(d, w));
     }

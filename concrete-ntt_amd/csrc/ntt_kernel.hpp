@@ -375,12 +375,11 @@ struct NttKernel {
         }
     }
     // the butterflies of the stage whose twiddle index h lies in [h0, h0 + CH)
-    template <int K, int GI, int CH, bool UNI, class R, bool CANON = false>
+    template <int K, int GI, int CH, bool UNI, class R>
     static __device__ __forceinline__ void stage_butterflies(R (&r)[E], const TwPair<T> (&w)[CH], int h0, const ModParams<T> &P) {
         constexpr uint32_t RM = S::RMASK[K], GM = S::GMASK[K];
         constexpr int b = nth_stage_bit(GM, GI), k = crank(RM, b);
         constexpr bool FIRST = !INV && !SUB && stage_no(K, GI) == 0;   // inputs of a whole forward transform: canonical (Bfly::fwd)
-        constexpr bool FIRST_INV = CANON && INV && !SUB && stage_no(K, GI) == 0;   // ... of a stand-alone inverse one (Bfly::inv)
 #pragma unroll
         for (int j = 0; j < E; ++j) {
             if ((j >> k) & 1) continue;
@@ -389,10 +388,10 @@ struct NttKernel {
             // twiddles that do not depend on the thread come from scalar loads and stay in SGPRs (never for the
             // sub-block kernels: their table prefix depends on the polynomial a thread works on)
             if constexpr (!std::is_same<R, T>::value) {
-                if constexpr (INV) BoxOps<CLS>::template inv<UNI, FIRST_INV>(r[j], r[j | (1 << k)], w[h - h0].w, w[h - h0].ws, P);
+                if constexpr (INV) BoxOps<CLS>::template inv<UNI>(r[j], r[j | (1 << k)], w[h - h0].w, w[h - h0].ws, P);
                 else BoxOps<CLS>::template fwd<UNI, FIRST>(r[j], r[j | (1 << k)], w[h - h0].w, w[h - h0].ws, P);
             } else if constexpr (INV)
-                Bfly<T, CLS>::template inv<UNI, FIRST_INV>(r[j], r[j | (1 << k)], w[h - h0].w, w[h - h0].ws, P);
+                Bfly<T, CLS>::template inv<UNI>(r[j], r[j | (1 << k)], w[h - h0].w, w[h - h0].ws, P);
             else
                 Bfly<T, CLS>::template fwd<UNI, FIRST>(r[j], r[j | (1 << k)], w[h - h0].w, w[h - h0].ws, P);
         }
@@ -402,8 +401,7 @@ struct NttKernel {
     // butterflies -- also applies the 1/N normalisation (Bfly::inv_norm).
     // R: the register form of a coefficient -- T itself, or (32-bit lazy class) a 64-bit "box" whose low word is the
     // value and whose high word is don't-care, the form in which x + y w + q (-p) is two v_mad_u64_u32 (BoxOps).
-    // CANON (inverse only): the transform's inputs are canonical memory words (stand-alone kernels): see Bfly::inv FIRST
-    template <int K, int GI, bool IMG = false, bool NORM = false, int TWC = 0, class R = T, bool CANON = false>
+    template <int K, int GI, bool IMG = false, bool NORM = false, int TWC = 0, class R = T>
     static __device__ __forceinline__ void stage(R (&r)[E], uint32_t ebase, uint32_t qpre, uint32_t depth,
                                                  const TwPair<T> *__restrict__ tw, const ModParams<T> &P,
                                                  uint32_t tid = 0, const TwPair<T> *img = nullptr) {
@@ -436,7 +434,6 @@ struct NttKernel {
         if constexpr (WAVE_UNI || (FAM == 2 && SUB && g.uniform)) toff = (uint32_t)__builtin_amdgcn_readfirstlane((int)toff);
         constexpr bool UNI = (g.uniform && (!SUB || FAM == 2)) || WAVE_UNI;
         constexpr bool FIRST = !INV && !SUB && stage_no(K, GI) == 0;   // inputs of a whole forward transform: canonical (Bfly::fwd)
-        constexpr bool FIRST_INV = CANON && INV && !SUB && stage_no(K, GI) == 0;
         constexpr bool CHUNKED = TWC > 0 && !UNI && NHI > TWC;
         constexpr int CH = CHUNKED ? TWC : NHI;
         if constexpr (CHUNKED && FAM == 2) {
@@ -449,12 +446,12 @@ struct NttKernel {
             for (int h0 = 0; h0 < NHI; h0 += 2 * CH) {
                 if (h0 + CH < NHI) stage_twiddles<K, GI, IMG, CH>(wb, h0 + CH, toff, tid, img, tw);
                 __builtin_amdgcn_sched_barrier(0);
-                stage_butterflies<K, GI, CH, UNI, R, CANON>(r, wa, h0, P);
+                stage_butterflies<K, GI, CH, UNI, R>(r, wa, h0, P);
                 __builtin_amdgcn_sched_barrier(0);
                 if (h0 + CH < NHI) {
                     if (h0 + 2 * CH < NHI) stage_twiddles<K, GI, IMG, CH>(wa, h0 + 2 * CH, toff, tid, img, tw);
                     __builtin_amdgcn_sched_barrier(0);
-                    stage_butterflies<K, GI, CH, UNI, R, CANON>(r, wb, h0 + CH, P);
+                    stage_butterflies<K, GI, CH, UNI, R>(r, wb, h0 + CH, P);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -478,10 +475,10 @@ struct NttKernel {
                     // twiddles that do not depend on the thread come from scalar loads and stay in SGPRs (never for the
                     // sub-block kernels: their table prefix depends on the polynomial a thread works on)
                     if constexpr (!std::is_same<R, T>::value) {
-                        if constexpr (INV) BoxOps<CLS>::template inv<UNI, FIRST_INV>(r[j], r[j | (1 << k)], w[h - h0].w, w[h - h0].ws, P);
+                        if constexpr (INV) BoxOps<CLS>::template inv<UNI>(r[j], r[j | (1 << k)], w[h - h0].w, w[h - h0].ws, P);
                         else BoxOps<CLS>::template fwd<UNI, FIRST>(r[j], r[j | (1 << k)], w[h - h0].w, w[h - h0].ws, P);
                     } else if constexpr (INV)
-                        Bfly<T, CLS>::template inv<UNI, FIRST_INV>(r[j], r[j | (1 << k)], w[h - h0].w, w[h - h0].ws, P);
+                        Bfly<T, CLS>::template inv<UNI>(r[j], r[j | (1 << k)], w[h - h0].w, w[h - h0].ws, P);
                     else
                         Bfly<T, CLS>::template fwd<UNI, FIRST>(r[j], r[j | (1 << k)], w[h - h0].w, w[h - h0].ws, P);
                 }
@@ -506,17 +503,17 @@ struct NttKernel {
         }
     }
 
-    template <int K, int GI, bool IMG, bool NORM, int TWC, class R, bool CANON = false>
+    template <int K, int GI, bool IMG, bool NORM, int TWC, class R>
     static __device__ __forceinline__ void stages_r(R (&r)[E], uint32_t ebase, uint32_t qpre, uint32_t depth,
                                                     const TwPair<T> *__restrict__ tw, const ModParams<T> &P, uint32_t tid,
                                                     const TwPair<T> *img) {
         if constexpr (GI < cpop(S::GMASK[K])) {
-            stage<K, GI, IMG, NORM, TWC, R, CANON>(r, ebase, qpre, depth, tw, P, tid, img);
-            stages_r<K, GI + 1, IMG, NORM, TWC, R, CANON>(r, ebase, qpre, depth, tw, P, tid, img);
+            stage<K, GI, IMG, NORM, TWC, R>(r, ebase, qpre, depth, tw, P, tid, img);
+            stages_r<K, GI + 1, IMG, NORM, TWC, R>(r, ebase, qpre, depth, tw, P, tid, img);
         }
     }
     // all register-resident stages of pass K
-    template <int K, int GI = 0, bool IMG = false, bool NORM = false, int TWC = 0, bool CANON = false>
+    template <int K, int GI = 0, bool IMG = false, bool NORM = false, int TWC = 0>
     static __device__ __forceinline__ void stages(T (&r)[E], uint32_t ebase, uint32_t qpre, uint32_t depth,
                                                   const TwPair<T> *__restrict__ tw, const ModParams<T> &P,
                                                   uint32_t tid = 0, const TwPair<T> *img = nullptr) {
@@ -524,11 +521,11 @@ struct NttKernel {
             uint64_t c[E];
 #pragma unroll
             for (int j = 0; j < E; ++j) c[j] = BoxOps<CLS>::box((uint32_t)r[j], P);
-            stages_r<K, GI, IMG, NORM, TWC, uint64_t, CANON>(c, ebase, qpre, depth, tw, P, tid, img);
+            stages_r<K, GI, IMG, NORM, TWC, uint64_t>(c, ebase, qpre, depth, tw, P, tid, img);
 #pragma unroll
             for (int j = 0; j < E; ++j) r[j] = (T)BoxOps<CLS>::unbox(c[j], P);
         } else {
-            stages_r<K, GI, IMG, NORM, TWC, T, CANON>(r, ebase, qpre, depth, tw, P, tid, img);
+            stages_r<K, GI, IMG, NORM, TWC, T>(r, ebase, qpre, depth, tw, P, tid, img);
         }
     }
 
@@ -545,7 +542,7 @@ struct NttKernel {
         } else {
             gather<RM>(r, (const T *)lds, ebase, true);
         }
-        stages<K, 0, false, false, 0, true>(r, ebase, qpre, depth, tw, P);   // CANON: memory words in (pass 0 of a whole inverse)
+        stages<K>(r, ebase, qpre, depth, tw, P);
         if constexpr (K == NPASS - 1) {
 #pragma unroll
             for (int j = 0; j < E; ++j) r[j] = INV ? Bfly<T, CLS>::finish_inv(r[j], P) : Bfly<T, CLS>::finish_fwd(r[j], P);
@@ -613,19 +610,18 @@ struct NttWp : NttKernel<T, LOGN, INV, CLS, false, FAM> {
     // global memory (L2), for kernels that walk several primes and cannot hold an image per prime
     // FIN: bring the outputs into [0, p) (what memory holds); fused kernels whose next step takes the class's lazy
     // register form (CLS_FP products) skip it
-    // CANON: see NttKernel::stage (stand-alone inverse kernels only)
-    template <int K, bool NORM = false, bool IMG = true, bool FIN = true, int TWC = 0, bool CANON = false>
+    template <int K, bool NORM = false, bool IMG = true, bool FIN = true, int TWC = 0>
     static __device__ __forceinline__ void pass(T (&r)[E], T *lds, uint32_t tid, const TwPair<T> *__restrict__ tw,
                                                 const TwPair<T> *img, const ModParams<T> &P) {
         constexpr uint32_t RM = S::RMASK[K], CM = FULL & ~RM;
         const uint32_t ebase = pdep<CM>(tid);
         if constexpr (K > 0) B::template gather<RM>(r, (const T *)lds, ebase, true);
-        B::template stages<K, 0, IMG, NORM, TWC, CANON>(r, ebase, 0u, 0u, tw, P, tid, img);
+        B::template stages<K, 0, IMG, NORM, TWC>(r, ebase, 0u, 0u, tw, P, tid, img);
         if constexpr (K < NPASS - 1) {
             if constexpr (K > 0) wsync();
             B::template scatter<RM>(r, lds, ebase, true);
             wsync();
-            pass<K + 1, NORM, IMG, FIN, TWC, CANON>(r, lds, tid, tw, img, P);
+            pass<K + 1, NORM, IMG, FIN, TWC>(r, lds, tid, tw, img, P);
         } else if constexpr (FIN) {
 #pragma unroll
             for (int j = 0; j < E; ++j) r[j] = INV ? Bfly<T, CLS>::finish_inv(r[j], P) : Bfly<T, CLS>::finish_fwd(r[j], P);
@@ -705,7 +701,7 @@ struct NttWp : NttKernel<T, LOGN, INV, CLS, false, FAM> {
                 B::template gather<RM0>(r, (const T *)lds, eb0, true);
                 wsync();
             }
-            pass<0, false, USE_IMG, true, USE_IMG ? TWC_IMG : 2, true>(r, lds, tidv, tw, img, P);   // CANON: the tile is memory words
+            pass<0, false, USE_IMG, true, USE_IMG ? TWC_IMG : 2>(r, lds, tidv, tw, img, P);
             if constexpr (RML != IO_RM) {  // output transpose
                 wsync();
                 B::template scatter<RML>(r, lds, ebL, true);

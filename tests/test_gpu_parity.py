@@ -359,6 +359,79 @@ def test_strict_class_transforms_mirror_the_reference_on_any_word(oracle, bits, 
     assert seen >= 4
 
 
+LAZY_ABOVE_POW2 = [(32, 536903681), (32, 268460033), (64, 2305843009214414849), (64, 1152921504607338497)]
+
+
+@pytest.mark.parametrize("bits,p", LAZY_ABOVE_POW2)
+def test_lazy_class_transforms_take_words_below_two_p(oracle, bits, p):
+    """Lazy class (p < 2^(B-2)), primes just ABOVE a power of two: the reference's mul_accumulate can leave a word in [p, 2p) there (its
+    Barrett estimate reaches 2p), and its butterflies reduce in every stage, the first included (src/prime64/
+    less_than_62bit.rs:117-154,271-310), so fwd / inv of such words still return the canonical residues.  Every kernel family (single pass,
+    persistent walk, wave blocks, one polynomial per workgroup) must do the same: words uniform in [0, 2p) in, the oracle's words out."""
+    from concrete_ntt_amd import prime32, prime64
+    mod = prime64 if bits == 64 else prime32
+    seen = 0
+    for n in ((16, 64, 1024, 2048, 4096, 16384) if bits == 64 else (32, 256, 1024, 2048, 4096)):
+        plan, ref = mod.Plan.try_new(n, p), oracle.Plan.try_new(n, p, bits)
+        assert (plan is None) == (ref is None)
+        if plan is None:
+            continue
+        a = oracle.fill_uniform(8 * n, 2 * p, 177 + n, bits)
+        assert int(a.max()) >= p
+        for name in ("fwd", "inv"):
+            want = a.copy()
+            getattr(ref, name + "_batch")(want, 4)
+            assert int(want.max()) < p
+            d = to_dev(a)
+            getattr(plan, name + "_batch")(d)
+            assert np.array_equal(to_host(d, plan.dtype), want), (name, bits, n, p)
+            seen += 1
+    assert seen >= 4
+
+
+@pytest.mark.parametrize("bits,n,p", [(32, 1024, 536903681), (32, 2048, 268460033)])
+def test_lazy_class_fwd_mul_accumulate_inv_with_noncanonical_accumulators(oracle, plans, oplans, bits, n, p):
+    """fwd -> mul_accumulate -> inv through the separate calls and through the composed / fused external_product, on primes where the
+    reference's mul_accumulate really does hand `inv` words in [p, 2p) (counted here on the oracle: the case is exercised, not assumed)."""
+    plan, ref = plans(bits, n, p), oplans(bits, n, p)
+    batch = 256
+    a = oracle.fill_uniform(batch * n, p, 3, bits)
+    key = oracle.fill_uniform(batch * n, p, 4, bits)       # NTT-domain words
+    acc = oracle.fill_uniform(batch * n, p, 5, bits)
+    fa = a.copy()
+    ref.fwd_batch(fa, 4)
+    want = acc.copy()
+    ref.mul_accumulate(want, fa, key)
+    assert int((want >= want.dtype.type(p)).sum()) > 0, "this prime / seed no longer produces a non-canonical accumulator"
+    wacc = want.copy()
+    ref.inv_batch(want, 4)
+    da, dk, dacc = to_dev(a), to_dev(key), to_dev(acc)
+    plan.fwd_batch(da)
+    plan.mul_accumulate_batch(dacc, da, dk)
+    assert np.array_equal(to_host(dacc, plan.dtype), wacc)
+    plan.inv_batch(dacc)
+    assert np.array_equal(to_host(dacc, plan.dtype), want)
+    # the chain entry point: nout = 5 takes the composed path (separate accumulate kernel + stand-alone inverse), nout = 2 the fused one
+    for J, O in ((2, 5), (2, 2), (3, 1)):
+        nb = 24
+        terms = a[: nb * J * n]
+        k = key[: J * O * n]
+        ft = terms.copy()
+        ref.fwd_batch(ft, 4)
+        wout = np.zeros(nb * O * n, dtype=a.dtype)
+        for e in range(nb):
+            for o in range(O):
+                acc1 = np.zeros(n, dtype=a.dtype)
+                for j in range(J):
+                    ref.mul_accumulate(acc1, np.ascontiguousarray(ft[(e * J + j) * n:(e * J + j + 1) * n]),
+                                       np.ascontiguousarray(k[(j * O + o) * n:(j * O + o + 1) * n]))
+                ref.inv(acc1)
+                wout[(e * O + o) * n:(e * O + o + 1) * n] = acc1
+        dout = to_dev(np.zeros(nb * O * n, dtype=a.dtype))
+        plan.external_product_batch(dout, to_dev(terms), to_dev(k), J, O, False)
+        assert np.array_equal(to_host(dout, plan.dtype), wout), (J, O)
+
+
 def run_wrap_case(oracle, plan, ref, bits, n, p, batch, require_wrap, seed=0):
     """(also driven with random strict-class primes above 2^B / 3 by tools/soak_random.py wrap)"""
     a = oracle.fill_uniform(batch * n, p, 3 + seed, bits)
