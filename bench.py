@@ -108,6 +108,51 @@ def cpu_baseline(n, p, seconds_budget=12.0):
     return out
 
 
+def verify_against_oracle(torch, cntt, plan, n, p, batch, dev, rank):
+    """Correctness gate of the printed number: AFTER the timed region, outside it, the timed step -- the
+    fused kernel -- and its three-launch form run once more on a FRESH seeded batch of the same size; polynomials {0, 4097, batch - 1}
+    of both results are compared, word for word, with the CPU oracle's fwd / mul_assign_normalize / inv of the same inputs (the call
+    pattern of the reference's own test, src/prime64.rs:1254-1266).  The oracle is the checker here, never the thing measured."""
+    import numpy as np
+    from oracle import pyoracle
+    ref = pyoracle.Plan.try_new(n, p, 64)
+    a = torch.empty(batch * n, dtype=torch.int64, device=dev)
+    b = torch.empty(batch * n, dtype=torch.int64, device=dev)
+    cntt.fill_uniform(a, p, 0x5EEDFACE + rank * batch * n)
+    cntt.fill_uniform(b, p, 0x5EEDC0DE + rank * batch * n)
+    picks = sorted({0, min(4097, batch - 1), batch - 1})
+    want = {}
+    for i in picks:
+        ha = a[i * n:(i + 1) * n].cpu().numpy().view(np.uint64).copy()
+        hb = b[i * n:(i + 1) * n].cpu().numpy().view(np.uint64).copy()
+        assert int(ha.max()) < p and int(hb.max()) < p
+        ref.fwd(ha)
+        ref.fwd(hb)
+        ref.mul_assign_normalize(ha, hb)
+        ref.inv(ha)
+        want[i] = ha
+    plan.fwd_batch(b)                      # B^, as in the timed loop
+    a2 = a.clone()
+    plan.mul_ntt_batch(a, b)               # the timed step
+    plan.fwd_batch(a2)                     # the same step as three launches
+    plan.mul_assign_normalize_batch(a2, b)
+    plan.inv_batch(a2)
+    torch.cuda.synchronize()
+    bad = []
+    for i in picks:
+        for name, t in (("fused", a), ("unfused", a2)):
+            got = t[i * n:(i + 1) * n].cpu().numpy().view(np.uint64)
+            if not np.array_equal(got, want[i]):
+                bad.append("%s step, polynomial %d: %d of %d words differ" % (name, i, int((got != want[i]).sum()), n))
+    same = bool(torch.equal(a, a2))        # and the two device paths agree on the WHOLE batch
+    if not same:
+        bad.append("fused and three-launch results differ somewhere in the batch")
+    del a, b, a2
+    return {"verified": not bad, "checker": "oracle/cntt_oracle.c (CPU restatement), polynomials %s of a fresh seeded batch of %d, "
+                                           "fused step and fwd / mul_assign_normalize / inv launches; whole batch fused == unfused"
+                                           % (picks, batch), "mismatches": bad}
+
+
 # ---------------------------------------------------------------------------------------------------------
 # launcher: `python bench.py --gpus N` with no WORLD_SIZE in the environment
 # ---------------------------------------------------------------------------------------------------------
@@ -596,13 +641,26 @@ def run_rank(args):
     achieved = moved / (fused_ms * 1e-3) / 1e9
     per_transform = 2 * alg_bytes / (fused_ms * 1e-3) / 1e9
 
+    # correctness gate (outside every timed region): rank-local, the line carries the AND over ranks
+    try:
+        verdict = verify_against_oracle(torch, cntt, plan, N, P62, batch, dev, rank)
+    except Exception as e:
+        verdict = {"verified": False, "checker": "oracle/cntt_oracle.c", "mismatches": ["verification could not run: %r" % (e,)]}
+    if dist is not None:
+        t = torch.tensor([1.0 if verdict["verified"] else 0.0], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        if float(t.item()) < 1.0 and verdict["verified"]:
+            verdict = dict(verdict, verified=False, mismatches=["another rank's verification failed"])
+
     def write_line(extras, with_cpu_baseline):
         if rank != 0:
             return
         units = world * 2 * batch * args.steps        # forward + inverse transforms, all ranks
         out = {
             "metric": METRIC,
-            "value": units / elapsed, "unit": "NTT/s",
+            # a number whose results do not match the oracle is not a number: value null, status 4 (see the end of run_rank)
+            "value": units / elapsed if verdict["verified"] else None, "unit": "NTT/s",
+            "verified": verdict["verified"], "verification": verdict,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -701,6 +759,9 @@ def run_rank(args):
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if not verdict["verified"]:
+        sys.stderr.write("bench.py rank %d: results differ from the oracle: %s\n" % (rank, verdict["mismatches"]))
+        sys.exit(4)
 
 
 def main():

@@ -32,3 +32,42 @@ def fill_uniform(tensor, bound, seed):
         raise TypeError("fill_uniform needs a device tensor")
     fn = lib().cntt_fill_uniform_u64 if esz == 8 else lib().cntt_fill_uniform_u32
     _lib.check(fn(ptr, count, bound, seed, stream))
+
+
+def debug_set(key, value):
+    """TESTING ONLY (include/cntt.h): kernel-selection switch `key` := value (-1: the library's default; key "reset": all defaults).
+    Results are identical for every setting.  The two class switches ("fp", "pm64") are read when a plan is created."""
+    _lib.check(lib().cntt_debug_set(key.encode(), int(value)))
+
+
+def debug_get(key):
+    import ctypes
+    v = ctypes.c_int(0)
+    _lib.check(lib().cntt_debug_get(key.encode(), ctypes.addressof(v)))
+    return v.value
+
+
+class debug_switches:
+    """with cntt.debug_switches(fp=0): ...  -- sets the switches for the block and restores the previous values afterwards."""
+
+    def __init__(self, **kw):
+        self._kw, self._old = kw, {}
+
+    def __enter__(self):
+        for k, v in self._kw.items():
+            self._old[k] = debug_get(k)
+            debug_set(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self._old.items():
+            debug_set(k, v)
+        return False
+
+
+def shard_bounds(batch, world, rank):
+    """[begin, end) of `rank`'s contiguous shard through the C ABI (cntt_shard_bounds; shard.py holds the same arithmetic in Python)."""
+    import ctypes
+    b, e = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    _lib.check(lib().cntt_shard_bounds(batch, world, rank, ctypes.addressof(b), ctypes.addressof(e)))
+    return b.value, e.value

@@ -124,6 +124,9 @@ def lib():
         "cntt_product_mul_accumulate_batch": (c_int, [c_vp, c_vp, c_vp, c_vp, c_sz, c_int, c_vp]),
         "cntt_product_external_product_batch": (c_int, [c_vp, c_vp, c_vp, c_vp, c_sz, c_sz, c_sz, c_int, c_u64, c_int,
                                                         c_int, c_vp]),
+        "cntt_debug_set": (c_int, [ctypes.c_char_p, c_int]),
+        "cntt_debug_get": (c_int, [ctypes.c_char_p, c_vp]),
+        "cntt_shard_bounds": (c_int, [c_sz, c_int, c_int, c_vp, c_vp]),
         "cntt_fill_uniform_u64": (c_int, [c_vp, c_sz, c_u64, c_u64, c_vp]),
         "cntt_fill_uniform_u32": (c_int, [c_vp, c_sz, c_u32, c_u64, c_vp]),
     }

@@ -54,6 +54,56 @@ extern "C" int cntt_device_count(void) {
     return n;
 }
 
+// ---------------------------------------------------------------------------------------------
+// testing only: the kernel-selection switchboard (ntt_launch.hpp DebugSwitch).  Plain atomics: set from a test or an A/B tool through
+// cntt_debug_set(), read where a path is chosen (the two class switches at plan creation, the rest at the call).  Nothing here, or
+// anywhere else in the library, reads the process environment.
+// ---------------------------------------------------------------------------------------------
+#include <atomic>
+namespace {
+struct SwitchDef { const char *name; int dflt; };
+constexpr SwitchDef kSwitches[DBG_COUNT] = {
+    {"fp", 1}, {"pm64", 1}, {"blk", 1}, {"mul32_blk", 1}, {"ext32_blk", 1}, {"ext_one", 1}, {"ext_split", -1}, {"native_acc", 1},
+    {"product_fused", -1}};
+std::atomic<int> g_switch[DBG_COUNT] = {{1}, {1}, {1}, {1}, {1}, {1}, {-1}, {1}, {-1}};
+int switch_index(const char *key) {
+    if (!key) return -1;
+    for (int i = 0; i < (int)DBG_COUNT; ++i)
+        if (std::strcmp(key, kSwitches[i].name) == 0) return i;
+    return -1;
+}
+}  // namespace
+int cntt::debug_switch(DebugSwitch key) { return g_switch[key].load(std::memory_order_relaxed); }
+extern "C" int cntt_debug_set(const char *key, int value) {
+    if (key && std::strcmp(key, "reset") == 0) {
+        for (int i = 0; i < (int)DBG_COUNT; ++i) g_switch[i].store(kSwitches[i].dflt);
+        return CNTT_OK;
+    }
+    const int i = switch_index(key);
+    if (i < 0) return fail(CNTT_EINVAL, "cntt_debug_set: unknown switch '%s'", key ? key : "(null)");
+    if (value < -1 || value > 1) return fail(CNTT_EINVAL, "cntt_debug_set: %s takes -1 (library default), 0 or 1", key);
+    g_switch[i].store(value < 0 ? kSwitches[i].dflt : value);
+    return CNTT_OK;
+}
+extern "C" int cntt_debug_get(const char *key, int *value) {
+    const int i = switch_index(key);
+    if (i < 0 || !value) return fail(CNTT_EINVAL, "cntt_debug_get: unknown switch '%s'", key ? key : "(null)");
+    *value = g_switch[i].load();
+    return CNTT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// batch partition over the devices of a node: contiguous shards, remainders to the low ranks -- the arithmetic of
+// concrete-ntt_amd/shard.py shard_bounds(), for C / Rust callers that drive several devices themselves (examples/multi_device.cpp)
+// ---------------------------------------------------------------------------------------------
+extern "C" int cntt_shard_bounds(size_t batch, int world, int rank, size_t *begin, size_t *end) {
+    if (world < 1 || rank < 0 || rank >= world || !begin || !end) return fail(CNTT_EINVAL, "cntt_shard_bounds: need 0 <= rank < world and non-NULL outputs");
+    const size_t base = batch / (size_t)world, rem = batch % (size_t)world, r = (size_t)rank;
+    *begin = r * base + (r < rem ? r : rem);
+    *end = *begin + base + (r < rem ? 1 : 0);
+    return CNTT_OK;
+}
+
 // Grid of the element-wise kernels (grid-stride loops: any grid is correct): one 256-thread block per 256 work items, NOT capped at
 // a few blocks per CU.  Measured (tools/pw_probe.py, 65536 x 1024 u64): mul_assign_normalize 0.374 -> 0.271 ms (4.3 -> 5.9 TB/s),
 // normalize 0.232 -> 0.178 ms (4.6 -> 6.0 TB/s) against the 2048-block persistent form; split / CRT / Garner kernels -4 ... -7 %.
@@ -205,12 +255,11 @@ template <class T, class PlanT> static int plan_new(size_t n, T p, PlanT **out) 
         mp.mont_r_shoup = shoup_of<T>(mp.mont_r, p);
     }
     // CLS_FP / CLS_FP51: 64-bit words, p < 2^50 / 2^51 (the classes of src/prime64/less_than_50bit.rs and
-    // less_than_51bit.rs).  CNTT_DISABLE_FP=1 keeps such plans on the integer butterflies (A/B measurements, and tests
+    // less_than_51bit.rs).  cntt_debug_set("fp", 0) keeps such plans on the integer butterflies (A/B measurements, and tests
     // that compare the two paths).
     mp.fp = 0;
     if constexpr (B == 64) {
-        const char *off = std::getenv("CNTT_DISABLE_FP");
-        if (p64 < ((uint64_t)1 << 51) && !(off && off[0] == '1')) {
+        if (p64 < ((uint64_t)1 << 51) && debug_switch(DBG_FP) != 0) {
             mp.fp = p64 < ((uint64_t)1 << 50) ? (uint32_t)CLS_FP : (uint32_t)CLS_FP51;
             const double pd = (double)p64;
             mp.fp_p = host::double_bits(pd);
@@ -223,10 +272,9 @@ template <class T, class PlanT> static int plan_new(size_t n, T p, PlanT **out) 
         }
     }
     // CLS_FPW: 32-bit words, p >= 2^31 (no lazy headroom in 32 bits: the Montgomery class otherwise): the LDS-resident
-    // transforms run on doubles (ntt_arith.hpp).  CNTT_DISABLE_FP=1 keeps the Montgomery class here too.
+    // transforms run on doubles (ntt_arith.hpp).  cntt_debug_set("fp", 0) keeps the Montgomery class here too.
     if constexpr (B == 32) {
-        const char *off = std::getenv("CNTT_DISABLE_FP");
-        if (mp.cls == CLS_GENERIC && !(off && off[0] == '1')) {
+        if (mp.cls == CLS_GENERIC && debug_switch(DBG_FP) != 0) {
             mp.fp = (uint32_t)CLS_FPW;
             const double pd = (double)p64;
             mp.fp_p = host::double_bits(pd);
@@ -238,13 +286,12 @@ template <class T, class PlanT> static int plan_new(size_t n, T p, PlanT **out) 
             mp.fp_last_w_q = host::double_bits(wl / pd);
         }
     }
-    // CLS_PM64: p = 2^64 - c with c < 2^32 (Solinas, and the largest primes below 2^64).  CNTT_DISABLE_PM64=1 keeps the
+    // CLS_PM64: p = 2^64 - c with c < 2^32 (Solinas, and the largest primes below 2^64).  cntt_debug_set("pm64", 0) keeps the
     // Montgomery class (A/B measurements and tests).
     mp.pm_c = 0;
     if constexpr (B == 64) {
-        const char *off = std::getenv("CNTT_DISABLE_PM64");
         const uint64_t c = (uint64_t)0 - p64;
-        if (p64 >= ((uint64_t)1 << 63) && c < ((uint64_t)1 << 32) && !(off && off[0] == '1')) {
+        if (p64 >= ((uint64_t)1 << 63) && c < ((uint64_t)1 << 32) && debug_switch(DBG_PM64) != 0) {
             mp.pm_c = (uint32_t)c;
             mp.pm_n_inv = pl->n_inv;
             mp.pm_last_w = (T)w_last;
@@ -461,7 +508,7 @@ static bool ext_split_wins(size_t word, int logn, int cls) {
     return true;
 }
 bool cntt::ext_split_enabled() {
-    static const int mode = [] { const char *e = std::getenv("CNTT_EXT_SPLIT"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+    const int mode = debug_switch(DBG_EXT_SPLIT);
     return mode < 0 ? g_ext_split_wins : mode == 1;
 }
 // mul_accumulate chain: out[b][o] (+)= inv(sum_j fwd(terms[b][j]) . key_ntt[j][o])  (device pointers).
@@ -843,8 +890,7 @@ static void build_acc_args(cntt_native *pl) {
     pl->has_acc = true;
 }
 bool cntt::native_acc_enabled() {
-    static const bool on = [] { const char *e = std::getenv("CNTT_NATIVE_ACC"); return !(e && e[0] == '0'); }();  // A/B runs, parity tests
-    return on;
+    return debug_switch(DBG_NATIVE_ACC) != 0;   // A/B runs, parity tests
 }
 
 extern "C" int cntt_native_plan_new(cntt_native_kind_t kind, size_t n, cntt_native_t **out) {
@@ -1363,8 +1409,8 @@ static hipError_t product_fused2_try(const cntt_product *pl, bool inv, uint64_t 
     // 8 % faster than the fused forward kernel (N = 2048, 32768 polynomials: 0.497 vs 0.542 ms) -- the fused one reads its
     // twiddles from L2 at three wavefronts per SIMD, the batched transforms from an LDS image -- while the fused inverse
     // (two transforms + Garner, no residue round trip) still wins (Replace 0.445 vs 0.522 ms; Accumulate 0.599 vs 0.582: a
-    // tie).  CNTT_PRODUCT_FUSED = 0 / 1 forces neither / both for A/B timing; results are identical (tests/test_product.py).
-    static const int force = [] { const char *e = std::getenv("CNTT_PRODUCT_FUSED"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+    // tie).  cntt_debug_set("product_fused", 0 / 1) forces neither / both for A/B timing; results are identical (tests/test_product.py).
+    const int force = debug_switch(DBG_PRODUCT_FUSED);
     if (force == 0 || (force < 0 && !inv)) return hipErrorNotSupported;
     const cntt_plan32 *q0 = pl->p32[0].get(), *q1 = pl->p32[1].get();
     const int cls = transform_class(q0);  // both primes above 2^31 (the reference's fast-path shape): CLS_FPW

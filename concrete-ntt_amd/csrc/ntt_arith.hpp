@@ -146,8 +146,35 @@ template <class T> __device__ __forceinline__ T umin(T a, T b) { return a < b ? 
 // x in [0, 2m) -> [0, m)
 template <class T> __device__ __forceinline__ T csub(T x, T m) { return umin<T>(x, x - m); }
 
-// min(x, x - p) for the strict class's butterflies: the borrow of the subtraction is the select condition (four instructions and two
-// s_nop for 64 bits; hipcc recomputes the condition with a 64-bit compare: five and the same two s_nop), p in scalar registers
+// ---------------------------------------------------------------------------------------------
+// 64-bit conditional subtraction of a value known to lie in [0, 2m), m < 2^63, WITHOUT the condition-code register (round 5): x - m then
+// lies in [-m, m), so its sign bit IS the borrow; v_ashrrev_i32 spreads it to a lane mask and two v_bitop3_b32 pick the result -- four
+// instructions at the plain rate, no scalar write, no wait state.  (The natural form -- v_cmp_lt_u64 + 2 v_cndmask_b32 -- writes VCC from
+// the vector ALU and reads it back: two wait states per read on gfx950.)  Measured A/B, profiles/r05_csub_mask_ab.txt: the same VALU count
+// (2010 against 2013 per thread and polynomial at N = 1024), half the padded wait states (188 against 374), the stages on registers 3 %
+// faster in the inverse direction, the whole kernels unchanged -- with eight independent butterflies per stage the scheduler had already
+// hidden the wait states.  Kept because it is never slower and frees VCC for the carry chains around it.
+// ---------------------------------------------------------------------------------------------
+// all-ones if bit 31 of w is set, else zero (v_ashrrev_i32)
+__device__ __forceinline__ uint32_t top_bit_mask(uint32_t w) { return (uint32_t)((int32_t)w >> 31); }
+// m ? a : b, bit by bit: two v_bitop3_b32 (truth table 0xca = (m & a) | (~m & b)).  Written as the builtin: from the plain expression hipcc
+// recognises a select on a sign and goes back to v_cmp_gt_i64 + v_cndmask; behind an opaque asm it pads a wait state after the mask.
+__device__ __forceinline__ uint64_t mask_select(uint32_t m, uint64_t a, uint64_t b) {
+    const uint32_t lo = __builtin_amdgcn_bitop3_b32(m, (uint32_t)a, (uint32_t)b, 0xca);
+    const uint32_t hi = __builtin_amdgcn_bitop3_b32(m, (uint32_t)(a >> 32), (uint32_t)(b >> 32), 0xca);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t csub_sign(uint64_t x, uint64_t neg_m) {
+    const uint64_t d = x + neg_m;   // v_lshl_add_u64
+    return mask_select(top_bit_mask((uint32_t)(d >> 32)), x, d);
+}
+
+// min(x, x - p) for the strict class's butterflies, ANY word x (the class mirrors the reference operation for operation, so the sign of
+// the difference is not enough): the borrow of the subtraction is the select condition (four instructions and two s_nop for 64 bits;
+// hipcc recomputes the condition with a 64-bit compare: five and the same two s_nop), p in scalar registers.
+// (Round 5 tried the VCC-free form here as well -- borrow rebuilt from the top words by v_bitop3_b32 0x8e, mask, two selects: five plain
+// instructions.  VALU count per thread 2363 -> 2562, padded wait states 891 -> 205, and the kernels 3 % SLOWER (316 -> 327 us forward,
+// 316 -> 320 us inverse per 65 536 transforms, profiles/r05_csub_mask_ab.txt): the extra instruction costs more than the hidden waits.)
 template <class T> __device__ __forceinline__ T csub_p(T x, T p) {
     if constexpr (sizeof(T) == 8) {
         const uint32_t x0 = (uint32_t)x, x1 = (uint32_t)(x >> 32), p0 = (uint32_t)p, p1 = (uint32_t)(p >> 32);
@@ -167,14 +194,15 @@ template <class T> __device__ __forceinline__ T csub_p(T x, T p) {
     }
 }
 
-// x in [0, 4p) -> [0, 2p): select (-2p or 0) and add -- v_cmp + 2 v_cndmask + v_lshl_add_u64 for 64 bits
+// x in [0, 4p) -> [0, 2p)   (p < 2^(B-2))
 template <class T> __device__ __forceinline__ T csub_two_p(T x, T two_p, T neg_two_p) {
-    if constexpr (sizeof(T) == 8) {
-        const T d = x + neg_two_p;
-        return x < two_p ? x : d;
-    } else {
-        return umin<T>(x, x - two_p);
-    }
+    if constexpr (sizeof(T) == 8) return csub_sign(x, neg_two_p);
+    else return umin<T>(x, x - two_p);
+}
+// x in [0, 2p) -> [0, p)   (p < 2^(B-1))
+template <class T> __device__ __forceinline__ T csub_one_p(T x, T p, T neg_p) {
+    if constexpr (sizeof(T) == 8) return csub_sign(x, neg_p);
+    else return umin<T>(x, x - p);
 }
 
 // Shoup product: y * w - floor(y * ws / 2^B) * p, in [0, 2p) for any y < 2^B  (needs p < 2^(B-1))
@@ -287,7 +315,7 @@ template <class T, int CLS> struct Bfly {
         if constexpr (CLS == CLS_LAZY) {
             x = shoup_mul<T, true>(x, P.n_inv, P.n_inv_shoup, P.neg_p);  // [0, 2p)
         } else if constexpr (CLS == CLS_STRICT) {
-            x = csub<T>(shoup_mul<T, true>(x, P.n_inv, P.n_inv_shoup, P.neg_p), P.p);  // (finish_inv is the identity for this class)
+            x = csub_one_p<T>(shoup_mul<T, true>(x, P.n_inv, P.n_inv_shoup, P.neg_p), P.p, P.neg_p);  // (finish_inv is the identity for this class)
         } else {
             x = mont_mul(x, P.n_inv, P.p, P.pinv_neg);  // n_inv field = N^-1 R^2: x / R * (N^-1 R^2) / R ... see mul_for_inv
         }
@@ -301,12 +329,12 @@ template <class T, int CLS> struct Bfly {
     static __device__ __forceinline__ T pre_inverse(T v, const ModParams<T> &) { return v; }
     // bring a value left by the last stage into [0, p)
     static __device__ __forceinline__ T finish_fwd(T v, const ModParams<T> &P) {
-        if constexpr (CLS == CLS_LAZY) return csub<T>(csub_two_p<T>(v, P.two_p, P.neg_two_p), P.p);   // (csub_p here: +-2 %, not kept)
+        if constexpr (CLS == CLS_LAZY) return csub_one_p<T>(csub_two_p<T>(v, P.two_p, P.neg_two_p), P.p, P.neg_p);
         if constexpr (CLS == CLS_STRICT) return csub_p<T>(v, P.p);
         return v;
     }
     static __device__ __forceinline__ T finish_inv(T v, const ModParams<T> &P) {
-        if constexpr (CLS == CLS_LAZY) return csub<T>(v, P.p);
+        if constexpr (CLS == CLS_LAZY) return csub_one_p<T>(v, P.p, P.neg_p);
         return v;   // (strict class: the reference's inverse butterflies leave their outputs as they are -- so does this one)
     }
 };

@@ -7,6 +7,25 @@
 #include "ntt_arith.hpp"
 
 namespace cntt {
+// The ONE switchboard behind cntt_debug_set() / cntt_debug_get() (include/cntt.h, "testing only"): kernel-selection overrides for A/B
+// timing and for the parity tests that compare two device paths.  Results are identical either way; nothing in the library reads the
+// process environment.  -1 = the library's own choice.  Defined in host.hip.
+enum DebugSwitch : int {
+    DBG_FP = 0,         // 1 (default): double-precision classes for u64 p < 2^51 / u32 p >= 2^31; 0: integer butterflies.  Read at plan creation.
+    DBG_PM64,           // 1 (default): fold-by-c class for p = 2^64 - c; 0: Montgomery class.  Read at plan creation.
+    DBG_BLK,            // 1 (default): wave-block walk for u64 N = 4096 ... 16384 / u32 N = 8192 ... 32768; 0: one polynomial per workgroup
+    DBG_MUL32_BLK,      // 1 (default): fused product of 32-bit words at N = 16384 / 32768 on the wave-block walk
+    DBG_EXT32_BLK,      // 1 (default): one-output mul_accumulate chain of 32-bit words on the wave-block walk
+    DBG_EXT_ONE,        // 1 (default): fused chain kernel for 32-bit words above N = 4096; 0: composed pipeline
+    DBG_EXT_SPLIT,      // -1 (default): split launches of 3 / 4 outputs where they measured faster; 0 never; 1 always
+    DBG_NATIVE_ACC,     // 1 (default): accumulating-CRT whole-product kernels; 0: the parked-tile kernels
+    DBG_PRODUCT_FUSED,  // -1 (default): product::Plan composed forward, fused inverse; 0 neither fused; 1 both fused
+    DBG_COUNT
+};
+int debug_switch(DebugSwitch key);
+}  // namespace cntt
+
+namespace cntt {
 
 // largest transform one workgroup keeps in LDS (gen_sched.py MAX_LDS_BYTES = 128 KiB)
 template <class T> struct MaxLdsLogN;
@@ -48,7 +67,7 @@ template <class T, int NOUT>
 hipError_t launch_ext_ntt_n(int logn, int cls, T *out, const T *terms, const T *key_ntt, const TwPair<T> *twf,
                             const TwPair<T> *twi, const ModParams<T> &P, uint32_t batch, uint32_t nterms, bool accumulate,
                             hipStream_t stream, uint32_t ostride);
-bool ext_split_enabled();   // CNTT_EXT_SPLIT=0: no split launches (A/B timing: the composed path instead)
+bool ext_split_enabled();   // switch "ext_split" = 0: no split launches (A/B timing: the composed path instead)
 template <class T>
 inline hipError_t launch_ext_ntt(int logn, int cls, T *out, const T *terms, const T *key_ntt, const TwPair<T> *twf,
                                  const TwPair<T> *twi, const ModParams<T> &P, uint32_t batch, uint32_t nterms, uint32_t nout,

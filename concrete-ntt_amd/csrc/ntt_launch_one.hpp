@@ -58,13 +58,7 @@ template <class T, bool INV, int CLS> static constexpr bool blk_prefetch() {
 // -2.4 %, 63-bit -2.4 ... -4.5 %, 2^64 - c -0.4 ... -2.7 %, the double-precision classes +-1 %; same-box A/B, profiles/r04_blk_twc_ab.txt)
 // (the strict class's inverse too: 106 ... 108 VGPRs on the reference-form butterflies, -1.1 ... -1.9 %)
 static constexpr int blk_twc(int logn, bool inv, int cls) { return 2; }
-static bool blk_enabled() {  // CNTT_DISABLE_BLK=1: one polynomial per workgroup, no persistent walk (A/B runs)
-    static const bool on = [] {
-        const char *e = std::getenv("CNTT_DISABLE_BLK");
-        return !(e && e[0] == '1');
-    }();
-    return on;
-}
+static bool blk_enabled() { return debug_switch(DBG_BLK) != 0; }   // (A/B runs: one polynomial per workgroup, no persistent walk)
 
 template <class T, int LOGN, bool INV, int CLS, bool SUB>
 static hipError_t launch_one(T *data, const TwPair<T> *tw, const ModParams<T> &P, uint32_t nsub, uint32_t depth,

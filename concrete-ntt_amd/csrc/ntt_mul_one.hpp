@@ -80,13 +80,7 @@ static hipError_t mul_blk_one(T *lhs, const T *rhs, const TwPair<T> *twf, const 
 constexpr bool mul32_blk_wins(int logn, int cls) {
     return (cls == CLS_LAZY && (logn == 14 || logn == 15)) || (cls == CLS_STRICT && logn == 15) || (cls == CLS_FPW && logn == 14);
 }
-static bool mul32_blk_enabled() {
-    static const bool on = [] {
-        const char *e = std::getenv("CNTT_MUL32_BLK");
-        return !(e && e[0] == '0');
-    }();
-    return on;
-}
+static bool mul32_blk_enabled() { return debug_switch(DBG_MUL32_BLK) != 0; }
 template <class T, int LOGN, int CLS>
 static hipError_t mul32_blk_one(T *lhs, const T *rhs, const TwPair<T> *twf, const TwPair<T> *twi, const ModParams<T> &P,
                                 uint32_t nsub, hipStream_t stream) {

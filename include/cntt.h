@@ -74,6 +74,30 @@ const char *cntt_last_error(void);      /* thread-local description of the last 
 int cntt_device_count(void);            /* number of visible HIP devices (0 if none / no driver) */
 const char *cntt_version(void);
 
+/* Contiguous partition of a batch of independent polynomials over `world` devices (the reference has no counterpart: it is
+ * single-threaded, src/lib.rs): rank r owns [begin, end), remainders go to the low ranks.  Pure arithmetic, no device call. */
+int cntt_shard_bounds(size_t batch, int world, int rank, size_t *begin, size_t *end);
+
+/* ------------------------------------------------------------------------------------- */
+/* TESTING ONLY -- kernel-selection overrides for A/B timing and device-vs-device parity   */
+/* tests.  Results are bit-identical for every setting; only the kernel that runs differs. */
+/* The library never reads the process environment.  No counterpart in the reference.      */
+/*   key              default  meaning                                                      */
+/*   "fp"                1     double-precision classes (u64 p < 2^51, u32 p >= 2^31); 0: integer butterflies.  Read at plan creation */
+/*   "pm64"              1     fold-by-c class for p = 2^64 - c, c < 2^32; 0: Montgomery class.  Read at plan creation                 */
+/*   "blk"               1     wave-block walk (u64 n = 4096..16384, u32 n = 8192..32768); 0: one polynomial per workgroup            */
+/*   "mul32_blk"         1     fused product of 32-bit words, n = 16384 / 32768, on the walk                                          */
+/*   "ext32_blk"         1     one-output mul_accumulate chain of 32-bit words on the walk                                            */
+/*   "ext_one"           1     fused chain kernel for 32-bit words above n = 4096; 0: composed pipeline                               */
+/*   "ext_split"        -1     split launches for 3 / 4 outputs where measured faster; 0 never; 1 always                              */
+/*   "native_acc"        1     accumulating-CRT whole-product kernels; 0: the parked-tile kernels                                     */
+/*   "product_fused"    -1     product::Plan: composed forward + fused inverse; 0 neither fused; 1 both                               */
+/* value -1 restores a switch's default; key "reset" restores all.  Process-wide, thread-safe (atomics); the two class switches are    */
+/* recorded in the plan at creation (cntt_prime*_plan_info().arith_class reports the class in use), the others are read per call.      */
+/* ------------------------------------------------------------------------------------- */
+int cntt_debug_set(const char *key, int value);
+int cntt_debug_get(const char *key, int *value);
+
 /* ===================================================================================== */
 /* prime64::Plan  (src/prime64.rs:221-236)                                                */
 /* ===================================================================================== */

@@ -51,6 +51,27 @@ pub fn version() -> String {
     unsafe { core::ffi::CStr::from_ptr(ffi::cntt_version()) }.to_string_lossy().into_owned()
 }
 
+/// `[begin, end)` of `rank`'s contiguous shard of a batch of independent polynomials split over `world` devices (remainders go to
+/// the low ranks).  Pure arithmetic; the caller drives the devices (one thread + one stream per device, `examples/multi_device.cpp`).
+pub fn shard_bounds(batch: usize, world: usize, rank: usize) -> core::ops::Range<usize> {
+    let (mut b, mut e) = (0usize, 0usize);
+    check(unsafe { ffi::cntt_shard_bounds(batch, world as c_int, rank as c_int, &mut b, &mut e) });
+    b..e
+}
+
+/// TESTING ONLY (`include/cntt.h`): kernel-selection switch `key` := `value` (`-1`: its default; key `"reset"`: all defaults).
+/// Results are identical for every setting; the library never reads the process environment.
+pub fn debug_set(key: &str, value: i32) {
+    let k = std::ffi::CString::new(key).expect("switch names hold no NUL");
+    check(unsafe { ffi::cntt_debug_set(k.as_ptr(), value as c_int) })
+}
+pub fn debug_get(key: &str) -> i32 {
+    let k = std::ffi::CString::new(key).expect("switch names hold no NUL");
+    let mut v: c_int = 0;
+    check(unsafe { ffi::cntt_debug_get(k.as_ptr(), &mut v) });
+    v as i32
+}
+
 /// Synthetic inputs generated on the device; `dev` is device memory.
 pub unsafe fn fill_uniform_u64(dev: *mut u64, count: usize, bound: u64, seed: u64, stream: Stream) {
     check(ffi::cntt_fill_uniform_u64(dev, count, bound, seed, stream))

@@ -112,6 +112,8 @@ def test_bench_json_contract():
     assert abs(rf["per_transform_frac"] / rf["frac"] - 4.0 / 3.0) < 1e-9
     assert rf["traffic"] is None and d["fwd_inv_standalone_value"] > 0   # no PMC figure at this batch
     assert rf["csrc_hash"] and len(rf["csrc_hash"]) == 16
+    # the correctness gate rides on the line: fused and three-launch step against the oracle on a fresh batch
+    assert d["verified"] is True and d["verification"]["mismatches"] == [] and "[0, 4097, 8191]" in d["verification"]["checker"]
 
 
 @pytest.mark.gpu

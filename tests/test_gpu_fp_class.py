@@ -10,6 +10,8 @@ import sys
 import numpy as np
 import pytest
 
+import concrete_ntt_amd as cntt
+
 from concrete_ntt_amd import prime64
 
 pytestmark = pytest.mark.gpu
@@ -152,7 +154,7 @@ def test_fp_mul_accumulate_chain(oracle, n, J, O, batch, accumulate, p):
 
 @pytest.mark.parametrize("P50,cls", [(P50, "3"), (P51, "4")])
 def test_fp_equals_integer_butterflies_on_a_large_batch(P50, cls):
-    """The same plan with CNTT_DISABLE_FP=1 (integer Shoup butterflies) in a child process: identical bytes for fwd, inv
+    """The same plan created under cntt_debug_set("fp", 0) (integer Shoup butterflies): identical bytes for fwd, inv
     and the fused product on 4096 random polynomials (a size the oracle would take long for is not needed: this is a
     device-vs-device check of two independent arithmetic paths)."""
     code = r'''
@@ -168,13 +170,12 @@ out = [plan.info().arith_class]
 x = a.clone(); plan.fwd_batch(x); out.append(hashlib.sha256(x.cpu().numpy().tobytes()).hexdigest())
 x = a.clone(); plan.inv_batch(x); out.append(hashlib.sha256(x.cpu().numpy().tobytes()).hexdigest())
 x = a.clone(); plan.mul_ntt_batch(x, b); out.append(hashlib.sha256(x.cpu().numpy().tobytes()).hexdigest())
-print(*out)
 ''' % P50
     res = []
-    for off in ("0", "1"):
-        env = dict(os.environ, CNTT_DISABLE_FP=off, PYTHONPATH=ROOT)
-        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
-        assert r.returncode == 0, r.stderr[-2000:]
-        res.append(r.stdout.split())
+    for on in (1, 0):   # the switch is read when the plan is created (include/cntt.h, "testing only"): same process, two plans
+        with cntt.debug_switches(fp=on):
+            ns = {}
+            exec(code, ns)
+        res.append([str(x) for x in ns["out"]])
     assert res[0][0] == cls and res[1][0] == "0"
     assert res[0][1:] == res[1][1:]

@@ -10,6 +10,8 @@ import sys
 import numpy as np
 import pytest
 
+import concrete_ntt_amd as cntt
+
 from concrete_ntt_amd import prime32
 
 pytestmark = pytest.mark.gpu
@@ -141,7 +143,7 @@ def test_fpw_fused_product_and_chain(oracle, n):
 
 
 def test_fpw_equals_montgomery_butterflies_on_a_large_batch():
-    """The same plan with CNTT_DISABLE_FP=1 (Montgomery class) in a child process: identical bytes for fwd and inv on 8192
+    """The same plan created under cntt_debug_set("fp", 0) (Montgomery class): identical bytes for fwd and inv on 8192
     random polynomials of N = 1024 (plus the fused product and a fused chain) and 512 of N = 16384 -- a device-vs-device
     check of two independent arithmetic paths."""
     code = r'''
@@ -164,14 +166,13 @@ for n, batch in ((1024, 8192), (16384, 512)):
         o = torch.zeros(64 * 2 * n, dtype=torch.int32, device="cuda")
         plan.external_product_batch(o, a[: 64 * 5 * n], b[: 5 * 2 * n], 5, 2)
         out.append(hashlib.sha256(o.cpu().numpy().tobytes()).hexdigest())
-print(*out)
 ''' % P32
     res = []
-    for off in ("0", "1"):
-        env = dict(os.environ, CNTT_DISABLE_FP=off, PYTHONPATH=ROOT)
-        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
-        assert r.returncode == 0, r.stderr[-2000:]
-        res.append(r.stdout.split())
+    for on in (1, 0):   # the switch is read when the plan is created (include/cntt.h, "testing only"): same process, two plans
+        with cntt.debug_switches(fp=on):
+            ns = {}
+            exec(code, ns)
+        res.append([str(x) for x in ns["out"]])
     # per size: class, sha(fwd), sha(inv); N = 1024 also sha(fused product), sha(fused chain)
     assert res[0][0] == "6" and res[0][5] == "6" and res[1][0] == "2" and res[1][5] == "2"
     assert len(res[0]) == 8 and [x for i, x in enumerate(res[0]) if i not in (0, 5)] == [x for i, x in enumerate(res[1]) if i not in (0, 5)]

@@ -86,7 +86,7 @@ def rust_prototypes():
 
 def test_every_entry_point_is_bound_with_matching_kinds():
     c, r = c_prototypes(), rust_prototypes()
-    assert len(c) == 84, len(c)
+    assert len(c) == 87, len(c)
     assert sorted(c) == sorted(r), (sorted(set(c) - set(r)), sorted(set(r) - set(c)))
     for name in c:
         cret, cargs = c[name]

@@ -7,6 +7,7 @@ name=$1; shift
 mkdir -p gpurun_out
 "$@" --tag new > gpurun_out/ab_${name}_new.jsonl
 cp concrete-ntt_amd/libcntt_hip.so /tmp/libcntt_new.so
+# whatever happens to the control run (failure, interrupt), the tree gets the NEW library back
+trap 'cp /tmp/libcntt_new.so concrete-ntt_amd/libcntt_hip.so' EXIT
 cp tools/_ctrl/libcntt_hip.so concrete-ntt_amd/libcntt_hip.so
 "$@" --tag old > gpurun_out/ab_${name}_old.jsonl
-cp /tmp/libcntt_new.so concrete-ntt_amd/libcntt_hip.so

@@ -2,10 +2,10 @@
 """A/B timing of the large-N prime64 transforms (N = 4096 ... 32768) on HBM-resident batches.
 
 One JSON line per (prime, n, direction): ns per transform, algorithmic bytes / time / 8 TB/s.  The kernel family is
-chosen by the library from the environment (CNTT_DISABLE_BLK=1: one polynomial per workgroup, no persistent walk), which is read once per
+chosen through the testing-only switchboard (CNTT_SWITCHES=blk=0 -> cntt_debug_set("blk", 0): one polynomial per workgroup, no persistent walk), which is read once per
 process -- run the script once per setting:
     python tools/blk_bench.py --tag blk            > gpurun_out/blk.jsonl
-    CNTT_DISABLE_BLK=1 python tools/blk_bench.py --tag onewg > gpurun_out/onewg.jsonl
+    CNTT_SWITCHES=blk=0 python tools/blk_bench.py --tag onewg > gpurun_out/onewg.jsonl
 """
 import argparse
 import json
@@ -18,6 +18,9 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 import concrete_ntt_amd as cntt  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import switches  # noqa: E402  (CNTT_SWITCHES="key=value,..." -> cntt_debug_set, tools/switches.py)
+switches.apply()
 from concrete_ntt_amd import prime64  # noqa: E402
 
 PRIMES = {"fp50": 1125899904679937, "fp51": 2251799813554177, "lazy62": 4611686018427322369,

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""A/B timing of the 32-bit-prime (p >= 2^31) paths: CLS_FPW against the Montgomery class (CNTT_DISABLE_FP=1).
-    python tools/fpw_bench.py ; CNTT_DISABLE_FP=1 python tools/fpw_bench.py"""
+"""A/B timing of the 32-bit-prime (p >= 2^31) paths: CLS_FPW against the Montgomery class (CNTT_SWITCHES=fp=0).
+    python tools/fpw_bench.py ; CNTT_SWITCHES=fp=0 python tools/fpw_bench.py"""
 import os
 import sys
 
@@ -8,6 +8,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
 import concrete_ntt_amd as cntt  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import switches  # noqa: E402  (CNTT_SWITCHES="key=value,..." -> cntt_debug_set, tools/switches.py)
+switches.apply()
 from concrete_ntt_amd import prime32  # noqa: E402
 
 P32 = 4293918721

@@ -13,6 +13,9 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 import concrete_ntt_amd as cntt  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import switches  # noqa: E402  (CNTT_SWITCHES="key=value,..." -> cntt_debug_set, tools/switches.py)
+switches.apply()
 from concrete_ntt_amd import prime32  # noqa: E402
 
 PRIMES = {"lazy30": 1073479681, "strict31": 2147352577, "fpw32": 4293918721}

@@ -20,6 +20,12 @@ static TwPair<uint64_t> *g_tw;
 static ModParams<uint64_t> g_P;
 static const uint32_t BATCH = 65536;
 static const int REPS = 200;
+#ifndef LAB_CLS
+#define LAB_CLS CLS_LAZY   // -DLAB_CLS=CLS_STRICT -DLAB_P=9223372036853661697ull: the 63-bit class
+#endif
+#ifndef LAB_P
+#define LAB_P 4611686018427322369ull
+#endif
 #ifndef LAB_WPW
 #define LAB_WPW 3  // waves per SIMD the persistent kernel is compiled for (= workgroups of 256 threads per CU)
 #endif
@@ -66,7 +72,7 @@ template <class K, int PASS = 0> __device__ __forceinline__ void all_stages(uint
 }
 template <bool INV> __global__ __launch_bounds__(256) void lab_alu_only(uint64_t *sink, const TwPair<uint64_t> *tw,
                                                                        const ModParams<uint64_t> P) {
-    using K = NttKernel<uint64_t, 10, INV, CLS_LAZY, false>;
+    using K = NttKernel<uint64_t, 10, INV, LAB_CLS, false>;
     LabStamp st;
     st.begin();
     uint64_t r[K::E];
@@ -81,7 +87,7 @@ template <bool INV> __global__ __launch_bounds__(256) void lab_alu_only(uint64_t
 }
 template <bool INV, int WPB, int WPW, int TWC = 0> __global__ __launch_bounds__(WPB, WPW) void lab_wp_stamped(
     uint64_t *data, const TwPair<uint64_t> *tw, const ModParams<uint64_t> P, uint32_t nsub) {
-    using K = NttWp<uint64_t, 10, INV, CLS_LAZY, WPB>;
+    using K = NttWp<uint64_t, 10, INV, LAB_CLS, WPB>;
     __shared__ __attribute__((aligned(16))) uint64_t lds[(size_t)K::PPB * K::B::LDS_WORDS_1];
     __shared__ __attribute__((aligned(16))) TwPair<uint64_t> img[K::B::IMG_ENTRIES];
     LabStamp st;
@@ -126,21 +132,21 @@ template <class F> static void timeit(const char *name, F launch) {
 }
 
 template <bool INV> static void product_kernel(const char *name) {  // what cntt_prime64_{fwd,inv}_batch launches at N=1024
-    using W = NttWp<uint64_t, 10, INV, CLS_LAZY, 256>;
+    using W = NttWp<uint64_t, 10, INV, LAB_CLS, 256>;
     const uint32_t ntiles = (BATCH + W::PPB - 1) / W::PPB;
     uint32_t grid = 256u * 3u;
     if (grid > ntiles) grid = ntiles;
     timeit(name, [&] {
-        hipLaunchKernelGGL((ntt_kernel_wp<uint64_t, 10, INV, CLS_LAZY, 256, 3>), dim3(grid), dim3(256), 0, 0, g_data, g_tw, g_P, BATCH);
+        hipLaunchKernelGGL((ntt_kernel_wp<uint64_t, 10, INV, LAB_CLS, 256, 3>), dim3(grid), dim3(256), 0, 0, g_data, g_tw, g_P, BATCH);
     });
 }
 template <bool INV> static void alu_only(const char *name) {
-    using K = NttKernel<uint64_t, 10, INV, CLS_LAZY, false>;
+    using K = NttKernel<uint64_t, 10, INV, LAB_CLS, false>;
     const uint32_t grid = BATCH / (256 / K::TPP);  // as many threads as the real transform of the batch
     timeit(name, [&] { hipLaunchKernelGGL((lab_alu_only<INV>), dim3(grid), dim3(256), 0, 0, g_data, g_tw, g_P); });
 }
 template <int WPB, int WPW, bool INV, int TWC = 0> static void wp_stamped(const char *name, int blocks_per_cu) {
-    using K = NttWp<uint64_t, 10, INV, CLS_LAZY, WPB>;
+    using K = NttWp<uint64_t, 10, INV, LAB_CLS, WPB>;
     const uint32_t ntiles = (BATCH + K::PPB - 1) / K::PPB;
     uint32_t grid = 256u * (uint32_t)blocks_per_cu;
     if (grid > ntiles) grid = ntiles;
@@ -156,9 +162,9 @@ template <bool INV> static bool check_wp(const std::vector<uint64_t> &src, uint3
     (void)hipMalloc(&b, bytes);
     (void)hipMemcpy(a, src.data(), bytes, hipMemcpyHostToDevice);
     (void)hipMemcpy(b, src.data(), bytes, hipMemcpyHostToDevice);
-    using K0 = NttKernel<uint64_t, 10, INV, CLS_LAZY, false>;
-    hipLaunchKernelGGL((ntt_kernel<uint64_t, 10, INV, CLS_LAZY, false>), dim3((batch + K0::PPB - 1) / K0::PPB), dim3(K0::BLOCK), 0, 0, a, g_tw, g_P, batch, 0u);
-    hipLaunchKernelGGL((ntt_kernel_wp<uint64_t, 10, INV, CLS_LAZY, 256, 3>), dim3(grid), dim3(256), 0, 0, b, g_tw, g_P, batch);
+    using K0 = NttKernel<uint64_t, 10, INV, LAB_CLS, false>;
+    hipLaunchKernelGGL((ntt_kernel<uint64_t, 10, INV, LAB_CLS, false>), dim3((batch + K0::PPB - 1) / K0::PPB), dim3(K0::BLOCK), 0, 0, a, g_tw, g_P, batch, 0u);
+    hipLaunchKernelGGL((ntt_kernel_wp<uint64_t, 10, INV, LAB_CLS, 256, 3>), dim3(grid), dim3(256), 0, 0, b, g_tw, g_P, batch);
     std::vector<uint64_t> ha((size_t)batch * 1024), hb((size_t)batch * 1024);
     (void)hipMemcpy(ha.data(), a, bytes, hipMemcpyDeviceToHost);
     (void)hipMemcpy(hb.data(), b, bytes, hipMemcpyDeviceToHost);
@@ -171,7 +177,7 @@ template <bool INV> static bool check_wp(const std::vector<uint64_t> &src, uint3
 
 int main() {
     const uint32_t n = 1024;
-    const uint64_t p = 4611686018427322369ull;
+    const uint64_t p = LAB_P;
     (void)hipMalloc(&g_data, (size_t)BATCH * n * 8);
     (void)hipMalloc(&g_tw, n * sizeof(TwPair<uint64_t>));
     (void)hipMalloc(&g_stamp, STAMP_WAVES * 16);

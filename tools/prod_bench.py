@@ -1,12 +1,15 @@
 #!/usr/bin/env python3
 """Timing of the product::Plan shape tfhe-rs uses (two 32-bit primes, src/product.rs:295-335 / :419-789): fused fwd and
 inv (Replace / Accumulate) kernels, N = 2048, 32768 polynomials.  A/B against the Montgomery class:
-    python tools/prod_bench.py ; CNTT_DISABLE_FP=1 python tools/prod_bench.py"""
+    python tools/prod_bench.py ; CNTT_SWITCHES=fp=0 python tools/prod_bench.py"""
 import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, concrete_ntt_amd as cntt
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import switches  # noqa: E402  (CNTT_SWITCHES="key=value,..." -> cntt_debug_set, tools/switches.py)
+switches.apply()
 from concrete_ntt_amd import product
 n, batch = 2048, 32768
 primes = [4294955009, 4294914049]

@@ -10,6 +10,9 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 import concrete_ntt_amd as cntt  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import switches  # noqa: E402  (CNTT_SWITCHES="key=value,..." -> cntt_debug_set, tools/switches.py)
+switches.apply()
 from concrete_ntt_amd import prime64  # noqa: E402
 
 PRIMES = {"lazy62": 4611686018427322369, "fp50": 1125899904679937, "strict63": 9223372036853661697,

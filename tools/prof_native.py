@@ -9,6 +9,9 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 import concrete_ntt_amd as cntt  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import switches  # noqa: E402  (CNTT_SWITCHES="key=value,..." -> cntt_debug_set, tools/switches.py)
+switches.apply()
 from concrete_ntt_amd import native64, native_binary64  # noqa: E402
 
 REPS = int(sys.argv[1]) if len(sys.argv) > 1 else 4

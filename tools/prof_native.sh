@@ -1,5 +1,5 @@
 #!/bin/bash
-# PMC passes over the whole-product kernels (tools/prof_native.py) for the current environment (CNTT_NATIVE_ACC,
+# PMC passes over the whole-product kernels (tools/prof_native.py) for the current environment (CNTT_SWITCHES=native_acc=0,
 # CNTT_ACC_VARIANT are inherited).  usage: tools/prof_native.sh outdir-name   (repo root, GPU box)
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
