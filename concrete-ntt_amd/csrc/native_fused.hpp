@@ -170,7 +170,8 @@ template <class SH> __device__ __forceinline__ typename SH::W crt_regs(const uin
 //               profiles/r02); otherwise it is re-read per prime (L2 / Infinity Cache hits at best)
 //   NF_TW_CHUNK two twiddle loads in flight per stage instead of all (ntt_kernel.hpp stage<>): fewer live registers
 //   NF_ROLL     the primes are a runtime loop instead of KP inlined copies of the three transforms
-enum : int { NF_GLOBAL = 1, NF_KEEP_L = 2, NF_KEEP_R = 4, NF_TW_CHUNK = 8, NF_ROLL = 16 };
+//   NF_LDS_R    (accumulating-CRT kernel) rhs is read from HBM ONCE and waits in thread-private LDS slots between the primes
+enum : int { NF_GLOBAL = 1, NF_KEEP_L = 2, NF_KEEP_R = 4, NF_TW_CHUNK = 8, NF_ROLL = 16, NF_LDS_R = 32 };
 
 template <int KIND, int LOGN, int BLK, int OPT>
 __device__ __forceinline__ void native_product(typename NativeShape<KIND>::W *__restrict__ prod,
@@ -438,7 +439,8 @@ __device__ __forceinline__ void native_product_acc(typename NativeShape<KIND>::W
                                                    const typename NativeShape<KIND>::W *__restrict__ lhs,
                                                    const typename NativeShape<KIND>::W *__restrict__ rhs,
                                                    const FusedTables<NativeShape<KIND>::KP> &F, const SplitArgs &S,
-                                                   const AccArgs &C, uint32_t batch, uint32_t sub0, uint32_t *lds_all) {
+                                                   const AccArgs &C, uint32_t batch, uint32_t sub0, uint32_t *lds_all,
+                                                   void *rstash_all = nullptr) {
     using SH = NativeShape<KIND>;
     using W = typename SH::W;
     using AW = AccWord<W>;
@@ -476,6 +478,10 @@ __device__ __forceinline__ void native_product_acc(typename NativeShape<KIND>::W
     };
     W lw[KEEP_L ? E : 1];
     RW rw[KEEP_R ? E : 1];
+    // NF_LDS_R: the rhs words of this thread, read from HBM once, wait in LDS slots only this thread touches ([j][thread]: conflict-free,
+    // no synchronisation) -- round 4 re-read rhs from HBM / L2 once per prime (PMC: 1.50 x the algorithmic bytes for C3, 1.34 x for C5)
+    constexpr bool LDS_R = (OPT & NF_LDS_R) != 0 && !KEEP_R;
+    RW *rst = reinterpret_cast<RW *>(rstash_all) + threadIdx.x;
     {
         const uint32_t ebase = pdep<FULL & ~RM0>(tid);
         if constexpr (KEEP_L) {
@@ -485,6 +491,10 @@ __device__ __forceinline__ void native_product_acc(typename NativeShape<KIND>::W
         if constexpr (KEEP_R) {
 #pragma unroll
             for (int j = 0; j < E; ++j) rw[j] = load_rhs(j, ebase);
+        }
+        if constexpr (LDS_R) {
+#pragma unroll
+            for (int j = 0; j < E; ++j) rst[j * BLK] = load_rhs(j, ebase);
         }
     }
     typename AW::A acc[E];
@@ -513,7 +523,10 @@ __device__ __forceinline__ void native_product_acc(typename NativeShape<KIND>::W
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < E; ++j) {
-            const RW w = KEEP_R ? rw[KEEP_R ? j : 0] : load_rhs(j, eb_r);
+            RW w;
+            if constexpr (KEEP_R) w = rw[KEEP_R ? j : 0];
+            else if constexpr (LDS_R) w = rst[j * BLK];
+            else w = load_rhs(j, eb_r);
             if constexpr (SH::BINARY) b[j] = w;
             else b[j] = split30_lazy<W>(w, S, C, i);
         }
@@ -575,7 +588,11 @@ __global__ __launch_bounds__(BLK, WPS) void native_polymul_kernel_acc(typename N
     constexpr int PPB = BLK / Wf::TPP;
     static_assert(BLK % Wf::TPP == 0 && PPB >= 1, "whole products per workgroup");
     __shared__ __attribute__((aligned(16))) uint32_t lds_all[(size_t)PPB * Wf::B::LDS_WORDS_1];
-    native_product_acc<KIND, LOGN, BLK, OPT>(prod, lhs, rhs, F, S, C, batch, blockIdx.x * PPB, lds_all);
+    using SH = NativeShape<KIND>;
+    using RW = typename std::conditional<SH::BINARY, uint32_t, typename SH::W>::type;
+    constexpr bool LDS_R = (OPT & NF_LDS_R) != 0 && (OPT & NF_KEEP_R) == 0;
+    __shared__ __attribute__((aligned(16))) RW rstash[LDS_R ? (size_t)Wf::E * BLK : 1];
+    native_product_acc<KIND, LOGN, BLK, OPT>(prod, lhs, rhs, F, S, C, batch, blockIdx.x * PPB, lds_all, rstash);
 }
 
 // products per workgroup / parked words per workgroup of a shape

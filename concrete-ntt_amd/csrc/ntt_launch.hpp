@@ -116,9 +116,12 @@ hipError_t launch_native_fused(int logn, void *prod, const void *lhs, const void
                                const void *tables_acc);
 // sizes / kinds of native_polymul_kernel_acc (no workspace, no parking)
 // (words of at most 64 bits up to n = 16384 -- 16 coefficients per thread, three words of state each; the 16-byte words of
-// native128 / native_binary128 -- five words of state -- up to n = 4096, where a product is at most 256 threads at 168 VGPRs)
+// native128 / native_binary128 -- five words of state -- up to n = 4096, where a product is at most 256 threads at 168 VGPRs, and, round 5,
+// native128 at n = 8192: 128 VGPRs with 15 spilled registers, 887 -> 763 ns per product; measured SLOWER than the parked-tile kernels and
+// therefore not enabled: native128 n = 16384 1990 against 1920 ns, native_binary128 n = 8192 433 against 387, n = 16384 1030 against 838
+// -- profiles/r05_native128_acc_ab.txt)
 constexpr bool native_fused_acc(int kind, int logn) {
-    return (kind == 2 || kind == 5) ? (logn >= 5 && logn <= 12) : (kind >= 0 && kind <= 4 && logn >= 5 && logn <= 14);
+    return kind == 2 ? (logn >= 5 && logn <= 13) : kind == 5 ? (logn >= 5 && logn <= 12) : (kind >= 0 && kind <= 4 && logn >= 5 && logn <= 14);
 }
 bool native_acc_enabled();
 inline int device_num_cus() {

@@ -70,6 +70,30 @@ template <class K, int PASS = 0> __device__ __forceinline__ void all_stages(uint
         all_stages<K, PASS + 1>(r, tw, P);
     }
 }
+// the same with THREAD-DEPENDENT twiddles (vector-register operands, read from the table in L2 by ordinary loads): what the butterflies cost when
+// their multiplicands are not scalar registers
+template <class K, int PASS = 0> __device__ __forceinline__ void all_stages_vtw(uint64_t (&r)[K::E], const TwPair<uint64_t> *tw,
+                                                                                const ModParams<uint64_t> &P, uint32_t tid) {
+    if constexpr (PASS < K::NPASS) {
+        constexpr uint32_t CM = K::FULL & ~K::S::RMASK[PASS];
+        K::template stages<PASS>(r, pdep<CM>(tid), 0u, 0u, tw, P);
+        all_stages_vtw<K, PASS + 1>(r, tw, P, tid);
+    }
+}
+template <bool INV> __global__ __launch_bounds__(256) void lab_alu_vtw(uint64_t *sink, const TwPair<uint64_t> *tw, const ModParams<uint64_t> P) {
+    using K = NttKernel<uint64_t, 10, INV, LAB_CLS, false>;
+    LabStamp st;
+    st.begin();
+    uint64_t r[K::E];
+#pragma unroll
+    for (int j = 0; j < K::E; ++j) r[j] = (uint64_t)(threadIdx.x * 77u + j);
+    all_stages_vtw<K>(r, tw, P, threadIdx.x & (K::TPP - 1));
+    uint64_t acc = 0;
+#pragma unroll
+    for (int j = 0; j < K::E; ++j) acc ^= r[j];
+    if (acc == 0x1234567ull) sink[0] = acc;
+    st.end();
+}
 template <bool INV> __global__ __launch_bounds__(256) void lab_alu_only(uint64_t *sink, const TwPair<uint64_t> *tw,
                                                                        const ModParams<uint64_t> P) {
     using K = NttKernel<uint64_t, 10, INV, LAB_CLS, false>;
@@ -145,6 +169,11 @@ template <bool INV> static void alu_only(const char *name) {
     const uint32_t grid = BATCH / (256 / K::TPP);  // as many threads as the real transform of the batch
     timeit(name, [&] { hipLaunchKernelGGL((lab_alu_only<INV>), dim3(grid), dim3(256), 0, 0, g_data, g_tw, g_P); });
 }
+template <bool INV> static void alu_vtw(const char *name) {
+    using K = NttKernel<uint64_t, 10, INV, LAB_CLS, false>;
+    const uint32_t grid = BATCH / (256 / K::TPP);
+    timeit(name, [&] { hipLaunchKernelGGL((lab_alu_vtw<INV>), dim3(grid), dim3(256), 0, 0, g_data, g_tw, g_P); });
+}
 template <int WPB, int WPW, bool INV, int TWC = 0> static void wp_stamped(const char *name, int blocks_per_cu) {
     using K = NttWp<uint64_t, 10, INV, LAB_CLS, WPB>;
     const uint32_t ntiles = (BATCH + K::PPB - 1) / K::PPB;
@@ -203,6 +232,8 @@ int main() {
     product_kernel<true>("inv product kernel (wp 256x3)");
     alu_only<false>("fwd ALU only (stages on registers)");
     alu_only<true>("inv ALU only (stages on registers)");
+    alu_vtw<false>("fwd ALU, per-thread twiddles (L2)");
+    alu_vtw<true>("inv ALU, per-thread twiddles (L2)");
     {
         std::vector<uint64_t> src(h.begin(), h.begin() + (size_t)1333 * 1024);
         printf("check wp vs one-polynomial-per-workgroup kernel: fwd %d inv %d\n", (int)check_wp<false>(src, 1333, 7),
