@@ -19,11 +19,15 @@ def _host(t, dtype):
     return t.cpu().numpy().view(dtype)
 
 
-def _random_prime(oracle, rng, bits, n, top=False):
+def _random_prime(oracle, rng, bits, n, top=False, above_pow2=False):
     lo_bits = max(n.bit_length() + 2, 12)
     while True:
         nbits = rng.randint(bits - 2, bits) if top else rng.randint(lo_bits, bits)  # top: the three widest classes
         hi = rng.randint(1 << (nbits - 1), (1 << nbits) - 1)
+        if above_pow2:
+            # just ABOVE a power of two: where the reference's Barrett estimate reaches 2p and its mul_accumulate leaves words in [p, 2p)
+            # (round 5, ADVICE round 4 -- primes drawn uniformly, or right below a power of two, never show it)
+            hi = (1 << (nbits - 1)) + rng.randint(1, max(4 * n, (1 << (nbits - 1)) >> 6))
         p = oracle.largest_prime_in_arithmetic_progression64(2 * n, 1, 0, hi)
         if p is not None and p > 2 * n:
             return p
@@ -38,7 +42,7 @@ def test_gpu_random_plans(oracle, seed):
     dt = np.uint64 if bits == 64 else np.uint32
     logn = rng.randint(4 if bits == 64 else 5, 15)
     n = 1 << logn
-    p = _random_prime(oracle, rng, bits, n, top=seed % 3 == 0)
+    p = _random_prime(oracle, rng, bits, n, top=seed % 3 == 0, above_pow2=seed % 5 == 4)
     plan, oplan = mod.Plan.try_new(n, p), oracle.Plan.try_new(n, p, bits)
     assert (plan is None) == (oplan is None), (n, p)
     if plan is None:
