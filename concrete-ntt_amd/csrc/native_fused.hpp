@@ -389,7 +389,15 @@ template <class W> __device__ __forceinline__ uint32_t split30_lazy(W w, const S
     if constexpr (sizeof(W) == 4) {
         return red32_lazy((uint32_t)w, p, A.one_shoup[k]);
     } else if constexpr (sizeof(W) == 8) {
-        return acc_red58((uint64_t)(uint32_t)((uint64_t)w >> 32) * c + (uint32_t)w, p, m60);
+        // t = hi c + lo with the WORD ITSELF as the multiply-add's addend: hi c + (lo + hi 2^32), then hi taken off the upper word again.
+        // (Written as hi * c + zext(lo), hipcc builds a (lo, 0) register pair per kept lhs word outside the prime loop: 48 registers for
+        // the 16 words instead of 32 -- the n = 2048 shapes spilled on it, round 5.)
+        const uint32_t hi = (uint32_t)((uint64_t)w >> 32);
+        uint64_t t;
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(t) : "v"(hi), "s"(c), "v"((uint64_t)w) : "vcc");
+        const uint32_t th = (uint32_t)(t >> 32) - hi, tl = (uint32_t)t;
+        const uint32_t q = __umulhi(__builtin_amdgcn_alignbit(th, tl, 28), m60);
+        return (uint32_t)mad_box<true>(q, 0u - p, t);   // low word: lo32(t) - q p (the upper word of the addend does not reach it)
     } else {
         uint32_t r = acc_red58((uint64_t)(uint32_t)(w.hi >> 32) * c + (uint32_t)w.hi, p, m60);   // r < 2^31: r c + limb < 2^58
         r = acc_red58((uint64_t)r * c + (uint32_t)(w.lo >> 32), p, m60);
@@ -484,6 +492,13 @@ __device__ __forceinline__ void native_product_acc(typename NativeShape<KIND>::W
     RW *rst = reinterpret_cast<RW *>(rstash_all) + threadIdx.x;
     {
         const uint32_t ebase = pdep<FULL & ~RM0>(tid);
+        if constexpr (LDS_R) {
+            // first, and fenced off from the lhs loads: in flight together the two operands' words do not fit the register budget (the
+            // n = 2048 shapes spilled 2 ... 4 registers once per thread -- 7 % extra HBM traffic on C5 through scratch memory)
+#pragma unroll
+            for (int j = 0; j < E; ++j) rst[j * BLK] = load_rhs(j, ebase);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         if constexpr (KEEP_L) {
 #pragma unroll
             for (int j = 0; j < E; ++j) lw[j] = word_at(lp0, j, ebase);
@@ -491,10 +506,6 @@ __device__ __forceinline__ void native_product_acc(typename NativeShape<KIND>::W
         if constexpr (KEEP_R) {
 #pragma unroll
             for (int j = 0; j < E; ++j) rw[j] = load_rhs(j, ebase);
-        }
-        if constexpr (LDS_R) {
-#pragma unroll
-            for (int j = 0; j < E; ++j) rst[j * BLK] = load_rhs(j, ebase);
         }
     }
     typename AW::A acc[E];
