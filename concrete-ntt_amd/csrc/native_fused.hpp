@@ -384,14 +384,18 @@ __device__ __forceinline__ uint32_t acc_mont_lazy(uint32_t a, uint32_t b, const 
     return (uint32_t)(((uint64_t)m * P.p + t) >> 32);
 }
 // value mod P_k in [0, 2 P_k) for a u32 / u64 / u128 word
-template <class W> __device__ __forceinline__ uint32_t split30_lazy(W w, const SplitArgs &A, const AccArgs &C, int k) {
+// KEPT: the word stays in registers across the primes (NF_KEEP_L)
+template <class W, bool KEPT = false> __device__ __forceinline__ uint32_t split30_lazy(W w, const SplitArgs &A, const AccArgs &C, int k) {
     const uint32_t p = (uint32_t)A.prime[k], c = A.c[k], m60 = C.m60[k];
     if constexpr (sizeof(W) == 4) {
         return red32_lazy((uint32_t)w, p, A.one_shoup[k]);
+    } else if constexpr (sizeof(W) == 8 && !KEPT) {
+        return acc_red58((uint64_t)(uint32_t)((uint64_t)w >> 32) * c + (uint32_t)w, p, m60);
     } else if constexpr (sizeof(W) == 8) {
-        // t = hi c + lo with the WORD ITSELF as the multiply-add's addend: hi c + (lo + hi 2^32), then hi taken off the upper word again.
+        // a word that is re-used by every prime: t = hi c + lo with the WORD ITSELF as the multiply-add's addend: hi c + (lo + hi 2^32), then hi taken off the upper word again.
         // (Written as hi * c + zext(lo), hipcc builds a (lo, 0) register pair per kept lhs word outside the prime loop: 48 registers for
-        // the 16 words instead of 32 -- the n = 2048 shapes spilled on it, round 5.)
+        // the 16 words instead of 32 -- the n = 2048 shapes spilled on it, round 5.  Words that are re-read per prime keep the plain form: the
+        // 128-VGPR shapes of n = 8192 / 16384 spill 9 registers with this one.)
         const uint32_t hi = (uint32_t)((uint64_t)w >> 32);
         uint64_t t;
         asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(t) : "v"(hi), "s"(c), "v"((uint64_t)w) : "vcc");
@@ -527,7 +531,7 @@ __device__ __forceinline__ void native_product_acc(typename NativeShape<KIND>::W
         const ModParams<uint32_t> &Pv = F.P[i];
 #pragma unroll
         for (int j = 0; j < E; ++j)
-            a[j] = split30_lazy<W>(KEEP_L ? lw[KEEP_L ? j : 0] : word_at(lp0, j, eb_l), S, C, i);
+            a[j] = split30_lazy<W, KEEP_L>(KEEP_L ? lw[KEEP_L ? j : 0] : word_at(lp0, j, eb_l), S, C, i);
         __builtin_amdgcn_sched_barrier(0);   // (the phases of a prime, and the primes, kept apart: overlapped they spill)
         Wf::template pass<0, false, false, false, TWC>(a, lds, tidf, F.twf[i], nullptr, Pv);   // FIN = false: lazy outputs in [0, 4p)
         Wf::wsync();
