@@ -108,7 +108,7 @@ def cpu_baseline(n, p, seconds_budget=12.0):
     return out
 
 
-def verify_against_oracle(torch, cntt, plan, n, p, batch, dev, rank):
+def verify_against_oracle(torch, cntt, plan, n, p, batch, dev, rank, corrupt=False):
     """Correctness gate of the printed number: AFTER the timed region, outside it, the timed step -- the
     fused kernel -- and its three-launch form run once more on a FRESH seeded batch of the same size; polynomials {0, 4097, batch - 1}
     of both results are compared, word for word, with the CPU oracle's fwd / mul_assign_normalize / inv of the same inputs (the call
@@ -138,6 +138,8 @@ def verify_against_oracle(torch, cntt, plan, n, p, batch, dev, rank):
     plan.mul_assign_normalize_batch(a2, b)
     plan.inv_batch(a2)
     torch.cuda.synchronize()
+    if corrupt:   # --selftest-corrupt: prove that the gate closes (tests/test_bench_contract.py)
+        a[picks[-1] * n + 5] ^= 1
     bad = []
     for i in picks:
         for name, t in (("fused", a), ("unfused", a2)):
@@ -148,7 +150,7 @@ def verify_against_oracle(torch, cntt, plan, n, p, batch, dev, rank):
     if not same:
         bad.append("fused and three-launch results differ somewhere in the batch")
     del a, b, a2
-    return {"verified": not bad, "checker": "oracle/cntt_oracle.c (CPU restatement), polynomials %s of a fresh seeded batch of %d, "
+    return {"verified": not bad, "ran": True, "checker": "oracle/cntt_oracle.c (CPU restatement), polynomials %s of a fresh seeded batch of %d, "
                                            "fused step and fwd / mul_assign_normalize / inv launches; whole batch fused == unfused"
                                            % (picks, batch), "mismatches": bad}
 
@@ -643,14 +645,17 @@ def run_rank(args):
 
     # correctness gate (outside every timed region): rank-local, the line carries the AND over ranks
     try:
-        verdict = verify_against_oracle(torch, cntt, plan, N, P62, batch, dev, rank)
+        verdict = verify_against_oracle(torch, cntt, plan, N, P62, batch, dev, rank, corrupt=args.selftest_corrupt)
     except Exception as e:
-        verdict = {"verified": False, "checker": "oracle/cntt_oracle.c", "mismatches": ["verification could not run: %r" % (e,)]}
+        # the checker itself could not run (no compiler on the box, out of memory for the fresh batch ...): the line says so
+        # ("verified": false, "ran": false) but keeps its measurement; only a MISMATCH voids the number
+        verdict = {"verified": False, "ran": False, "checker": "oracle/cntt_oracle.c", "mismatches": [],
+                   "error": "verification could not run: %r" % (e,)}
     if dist is not None:
         t = torch.tensor([1.0 if verdict["verified"] else 0.0], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         if float(t.item()) < 1.0 and verdict["verified"]:
-            verdict = dict(verdict, verified=False, mismatches=["another rank's verification failed"])
+            verdict = dict(verdict, verified=False, mismatches=["another rank's verification failed or could not run"])
 
     def write_line(extras, with_cpu_baseline):
         if rank != 0:
@@ -659,7 +664,7 @@ def run_rank(args):
         out = {
             "metric": METRIC,
             # a number whose results do not match the oracle is not a number: value null, status 4 (see the end of run_rank)
-            "value": units / elapsed if verdict["verified"] else None, "unit": "NTT/s",
+            "value": units / elapsed if not verdict["mismatches"] else None, "unit": "NTT/s",
             "verified": verdict["verified"], "verification": verdict,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
@@ -759,9 +764,11 @@ def run_rank(args):
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    if not verdict["verified"]:
+    if verdict["mismatches"]:
         sys.stderr.write("bench.py rank %d: results differ from the oracle: %s\n" % (rank, verdict["mismatches"]))
         sys.exit(4)
+    if not verdict["verified"]:
+        sys.stderr.write("bench.py rank %d: %s\n" % (rank, verdict.get("error")))
 
 
 def main():
@@ -786,6 +793,9 @@ def main():
     ap.add_argument("--dry-run", action="store_true",
                     help="launch / rendezvous plumbing only (gloo, no GPU, no transform); prints a line with value null")
     ap.add_argument("--launch-timeout", type=int, default=1500, help="seconds the launcher waits for its ranks")
+    ap.add_argument("--selftest-corrupt", action="store_true",
+                    help="testing only: flip one bit of the verified batch before it is compared with the oracle -- the line must come out "
+                         "with value null, verified false and exit status 4")
     ap.add_argument("--extras-strict", action="store_true",
                     help="exit with status 3 (instead of 0) when the extras watchdog fires")
     ap.add_argument("--extras-timeout", type=int, default=420,

@@ -32,7 +32,16 @@ NATIVE_INFO = {  # kind: (nprimes, word bytes, is52, binary)
 def build(native=False):
     """Compile the C restatement (building the checker is not using it)."""
     target = "native" if native else "all"
-    subprocess.run(["make", "-s", "-C", _HERE, target], check=True)
+    # several processes may arrive here at once (the ranks of `bench.py --gpus N` verify their results against this checker): one builds,
+    # the others wait for it
+    import fcntl
+    os.makedirs(os.path.join(_HERE, "_build"), exist_ok=True)
+    with open(os.path.join(_HERE, "_build", ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            subprocess.run(["make", "-s", "-C", _HERE, target], check=True)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return os.path.join(_HERE, "_build", "libcntt_oracle_native.so" if native else "libcntt_oracle.so")
 
 

@@ -117,6 +117,18 @@ def test_bench_json_contract():
 
 
 @pytest.mark.gpu
+def test_bench_gate_closes_on_a_wrong_word():
+    """The correctness gate of the printed number: with one bit of the verified batch flipped the line carries no value, says why, and the
+    command fails (status 4) -- SURVEY 8(d) / BASELINE.md 3 "correctness gate before any timing is accepted"."""
+    r = subprocess.run([sys.executable, BENCH, "--steps", "2", "--warmup", "1", "--ramp-seconds", "0.2", "--batch", "8192", "--no-extra",
+                        "--no-cpu-baseline", "--selftest-corrupt"], capture_output=True, text=True, cwd=ROOT, env=clean_env(), timeout=600)
+    assert r.returncode == 4, (r.returncode, r.stderr[-1500:])
+    d = one_json_line(r.stdout)
+    assert d["value"] is None and d["verified"] is False and d["verification"]["ran"] is True
+    assert any("polynomial 8191" in m for m in d["verification"]["mismatches"]), d["verification"]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("launcher", ["self", "torchrun"])
 def test_two_ranks_on_the_gpu_box(launcher):
     """world_size 2 through both launch forms; gloo so that both ranks may share the box's single GPU.  Checks the
