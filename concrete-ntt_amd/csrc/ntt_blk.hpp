@@ -69,9 +69,9 @@ struct NttBlk {
                 constexpr uint32_t WIN = BYTE & ~4095u, IMM = BYTE & 4095u;
                 const char *base = reinterpret_cast<const char *>(tile) + WIN;
                 if constexpr (B16)
-                    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(v[JV]) : "v"(voff), "s"(base), "n"(IMM) : "memory");
+                    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3 nt" : "=v"(v[JV]) : "v"(voff), "s"(base), "n"(IMM) : "memory");
                 else
-                    asm volatile("global_load_dwordx2 %0, %1, %2 offset:%3" : "=v"(v[JV]) : "v"(voff), "s"(base), "n"(IMM) : "memory");
+                    asm volatile("global_load_dwordx2 %0, %1, %2 offset:%3 nt" : "=v"(v[JV]) : "v"(voff), "s"(base), "n"(IMM) : "memory");
                 issue<JV + 1>(v, tile, voff);
             }
         }

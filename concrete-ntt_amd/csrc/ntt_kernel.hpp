@@ -161,6 +161,9 @@ struct NttKernel {
     }
 
     // ---- tile-relative global addressing (persistent kernels) -----------------------------------
+    // Batch data streams through the chip exactly once per launch: every tile load and store carries the non-temporal hint (round 5:
+    // loads AND stores together -3 % on the N = 1024 transforms, either alone nothing -- profiles/r05_nt_hint_ab.txt; the plan tables keep
+    // the default policy, they are what L2 should hold).
     // A tile's address is a workgroup-uniform base (an SGPR pair) plus ONE 32-bit byte offset per thread: the
     // compiler selects global_load / global_store with an saddr operand, and no 64-bit per-thread pointers live in
     // VGPRs across the butterflies.
@@ -203,12 +206,12 @@ struct NttKernel {
         for (int j = 0; j < E; j += NV) {
             const uint32_t off = voff + cdep((uint32_t)j, RM) * (uint32_t)sizeof(T);
             if constexpr (NV == 1) {
-                *reinterpret_cast<T *>(reinterpret_cast<char *>(tile) + off) = r[j];
+                __builtin_nontemporal_store(r[j], reinterpret_cast<T *>(reinterpret_cast<char *>(tile) + off));
             } else {
                 V v;
 #pragma unroll
                 for (int i = 0; i < NV; ++i) v[i] = r[j + i];
-                *reinterpret_cast<V *>(reinterpret_cast<char *>(tile) + off) = v;
+                __builtin_nontemporal_store(v, reinterpret_cast<V *>(reinterpret_cast<char *>(tile) + off));
             }
         }
     }
@@ -234,7 +237,7 @@ struct NttKernel {
             constexpr uint32_t BYTE = cdep((uint32_t)(JV * MAXV), RM) * (uint32_t)sizeof(T);
             constexpr uint32_t WIN = BYTE & ~4095u, IMM = BYTE & 4095u;
             const char *base = reinterpret_cast<const char *>(tile) + WIN;
-            asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(v[JV]) : "v"(voff), "s"(base), "n"(IMM) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3 nt" : "=v"(v[JV]) : "v"(voff), "s"(base), "n"(IMM) : "memory");
             gather_async<RM, JV + 1>(v, tile, voff);
         }
     }
