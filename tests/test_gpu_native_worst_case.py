@@ -1,7 +1,7 @@
 """Deterministic worst cases of the accumulating-CRT whole-product kernel (native_polymul_kernel_acc, csrc/native_fused.hpp; VERDICT
 round 4).  The kernel decides which multiple of M = P_0 ... P_{k-1} to subtract by ROUNDING a 27-bit fixed-point sum of gamma_i / P_i;
 the exact sum is k + c / M for the exact integer coefficient c of the product, so the rounding is safe while |c| / M plus the
-fixed-point error stays below 1/2 (DESIGN 3.2: 2^-5.9 + k 2^-26).  Uniform random words never come near the bound on |c|; these
+fixed-point error stays below 1/2 (DESIGN 3.3: 2^-5.9 + k 2^-26).  Uniform random words never come near the bound on |c|; these
 patterns reach it:
     all-ones (.) all-ones          c_j = A^2 (2j + 2 - n): the largest positive value n A^2 at j = n - 1, -(n - 2) A^2 at j = 0
     all-ones (.) (0, A, A, ... A)  c_0 = -(n - 1) A^2: the most negative coefficient a negacyclic product can have
