@@ -31,31 +31,34 @@ __global__ __launch_bounds__(256) void pointwise_kernel(T *__restrict__ a, const
             if constexpr (OP == PW_ADD) va[k] = add_mod<T>(va[k], vb[k], P.p);
         }
     };
-    // two vectors per thread in flight (the loads of the second are issued before the arithmetic of the first)
+    // two vectors per thread in flight (the loads of the second are issued before the arithmetic of the first).  The operands stream
+    // through once: non-temporal loads and stores (round 5, like the transforms' tiles).
+    auto ld = [](const T *base, size_t i) { return __builtin_nontemporal_load(reinterpret_cast<const V *>(base) + i); };
+    auto st = [](T *base, size_t i, const V &v) { __builtin_nontemporal_store(v, reinterpret_cast<V *>(base) + i); };
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     for (; i + stride < nvec; i += 2 * stride) {
-        V va0 = reinterpret_cast<const V *>(a)[i], va1 = reinterpret_cast<const V *>(a)[i + stride];
+        V va0 = ld(a, i), va1 = ld(a, i + stride);
         V vb0 = va0, vb1 = va1, vc0 = va0, vc1 = va1;
         if constexpr (OP != PW_NORMALIZE) {
-            vb0 = reinterpret_cast<const V *>(b)[i];
-            vb1 = reinterpret_cast<const V *>(b)[i + stride];
+            vb0 = ld(b, i);
+            vb1 = ld(b, i + stride);
         }
         if constexpr (OP == PW_MUL_ACCUMULATE) {
-            vc0 = reinterpret_cast<const V *>(c)[i];
-            vc1 = reinterpret_cast<const V *>(c)[i + stride];
+            vc0 = ld(c, i);
+            vc1 = ld(c, i + stride);
         }
         apply(va0, vb0, vc0);
         apply(va1, vb1, vc1);
-        reinterpret_cast<V *>(a)[i] = va0;
-        reinterpret_cast<V *>(a)[i + stride] = va1;
+        st(a, i, va0);
+        st(a, i + stride, va1);
     }
     for (; i < nvec; i += stride) {
-        V va = reinterpret_cast<const V *>(a)[i];
+        V va = ld(a, i);
         V vb = va, vc = va;
-        if constexpr (OP != PW_NORMALIZE) vb = reinterpret_cast<const V *>(b)[i];
-        if constexpr (OP == PW_MUL_ACCUMULATE) vc = reinterpret_cast<const V *>(c)[i];
+        if constexpr (OP != PW_NORMALIZE) vb = ld(b, i);
+        if constexpr (OP == PW_MUL_ACCUMULATE) vc = ld(c, i);
         apply(va, vb, vc);
-        reinterpret_cast<V *>(a)[i] = va;
+        st(a, i, va);
     }
     // tail (count not a multiple of the vector width)
     for (size_t i = nvec * NV + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
