@@ -13,7 +13,10 @@ namespace cntt {
 // ---------------------------------------------------------------------------------------------
 enum : int { PW_MUL_NORMALIZE = 0, PW_NORMALIZE = 1, PW_MUL_ACCUMULATE = 2, PW_ADD = 3 };
 
-template <class T, int OP>
+// STREAM: the operands are larger than the 256 MiB Infinity Cache and pass through once -- non-temporal loads and stores (round 5:
+// -5 % on 512 MiB operands).  Operands that fit the cache keep the default policy: with the hint a 128 MiB batch that the previous kernel
+// left in the cache is fetched from HBM again (+12 ... +17 %, profiles/r05_small_batch_ab.txt).  The launcher decides (host.hip).
+template <class T, int OP, bool STREAM = false>
 __global__ __launch_bounds__(256) void pointwise_kernel(T *__restrict__ a, const T *__restrict__ b,
                                                         const T *__restrict__ c, const ModParams<T> P, size_t count) {
     // OP == MUL_NORMALIZE: a <- a*b*ninv ; NORMALIZE: a <- a*ninv ; MUL_ACCUMULATE: a <- a + b*c ; ADD: a <- a + b
@@ -31,10 +34,15 @@ __global__ __launch_bounds__(256) void pointwise_kernel(T *__restrict__ a, const
             if constexpr (OP == PW_ADD) va[k] = add_mod<T>(va[k], vb[k], P.p);
         }
     };
-    // two vectors per thread in flight (the loads of the second are issued before the arithmetic of the first).  The operands stream
-    // through once: non-temporal loads and stores (round 5, like the transforms' tiles).
-    auto ld = [](const T *base, size_t i) { return __builtin_nontemporal_load(reinterpret_cast<const V *>(base) + i); };
-    auto st = [](T *base, size_t i, const V &v) { __builtin_nontemporal_store(v, reinterpret_cast<V *>(base) + i); };
+    // two vectors per thread in flight (the loads of the second are issued before the arithmetic of the first)
+    auto ld = [](const T *base, size_t i) -> V {
+        if constexpr (STREAM) return __builtin_nontemporal_load(reinterpret_cast<const V *>(base) + i);
+        else return reinterpret_cast<const V *>(base)[i];
+    };
+    auto st = [](T *base, size_t i, const V &v) {
+        if constexpr (STREAM) __builtin_nontemporal_store(v, reinterpret_cast<V *>(base) + i);
+        else reinterpret_cast<V *>(base)[i] = v;
+    };
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     for (; i + stride < nvec; i += 2 * stride) {
         V va0 = ld(a, i), va1 = ld(a, i + stride);

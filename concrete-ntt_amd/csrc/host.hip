@@ -422,14 +422,17 @@ template <class T> static int ntt_device(const PrimePlan<T> *pl, T *d, size_t ba
     const uint32_t nsub = (uint32_t)(batch << depth);
     const size_t nbfly = batch * (pl->n / 2);
     const int tcls = transform_class(pl);
+    // per-launch copy of the plan's parameters: a batch beyond the 256 MiB Infinity Cache streams (ModParams::stream, ntt_kernel.hpp)
+    ModParams<T> mp = pl->mp;
+    mp.stream = batch * pl->n * sizeof(T) > ((size_t)384 << 20) ? 1u : 0u;
     hipError_t e;
     if (depth == 1 && batch < ((size_t)1 << 32)) {
         // one size past the LDS-resident ones: a single-pass kernel exists for 64-bit words (Ntt32k), in the plan's
         // 64-bit-only class where it has one (those tables exist at every size)
         int c1 = tcls;
         if constexpr (sizeof(T) == 8) c1 = pl->mp.fp ? (int)pl->mp.fp : pl->mp.pm_c ? (int)CLS_PM64 : tcls;
-        e = inv ? launch_ntt<T, true>(pl->logn, c1, d, alt_tables(c1) ? t.inv_fp : t.inv, pl->mp, (uint32_t)batch, 0u, st)
-                : launch_ntt<T, false>(pl->logn, c1, d, alt_tables(c1) ? t.fwd_fp : t.fwd, pl->mp, (uint32_t)batch, 0u, st);
+        e = inv ? launch_ntt<T, true>(pl->logn, c1, d, alt_tables(c1) ? t.inv_fp : t.inv, mp, (uint32_t)batch, 0u, st)
+                : launch_ntt<T, false>(pl->logn, c1, d, alt_tables(c1) ? t.fwd_fp : t.fwd, mp, (uint32_t)batch, 0u, st);
         if (e == hipSuccess) return CNTT_OK;
         (void)hipGetLastError();
         if (e != hipErrorNotSupported && e != hipErrorInvalidValue)
@@ -437,9 +440,9 @@ template <class T> static int ntt_device(const PrimePlan<T> *pl, T *d, size_t ba
     }
     if (!inv) {
         for (int s = 0; s < depth; ++s) global_stage<T, false>(d, t.fwd, pl->mp, (uint32_t)pl->logn, (uint32_t)s, nbfly, false, st);
-        e = launch_ntt<T, false>(sub_logn, tcls, d, alt_tables(tcls) ? t.fwd_fp : t.fwd, pl->mp, nsub, (uint32_t)depth, st);
+        e = launch_ntt<T, false>(sub_logn, tcls, d, alt_tables(tcls) ? t.fwd_fp : t.fwd, mp, nsub, (uint32_t)depth, st);
     } else {
-        e = launch_ntt<T, true>(sub_logn, tcls, d, alt_tables(tcls) ? t.inv_fp : t.inv, pl->mp, nsub, (uint32_t)depth, st);
+        e = launch_ntt<T, true>(sub_logn, tcls, d, alt_tables(tcls) ? t.inv_fp : t.inv, mp, nsub, (uint32_t)depth, st);
         for (int s = depth - 1; s >= 0 && e == hipSuccess; --s)
             global_stage<T, true>(d, t.inv, pl->mp, (uint32_t)pl->logn, (uint32_t)s, nbfly, s == 0, st);
     }
@@ -452,7 +455,12 @@ template <class T, int OP>
 static int pointwise_device(const PrimePlan<T> *pl, T *a, const T *b, const T *c, size_t count, hipStream_t st) {
     if (count == 0) return CNTT_OK;
     const size_t nv = count / (16 / sizeof(T)) + 1;
-    hipLaunchKernelGGL((pointwise_kernel<T, OP>), dim3(ew_grid(nv)), dim3(256), 0, st, a, b, c, pl->mp, count);
+    // working set of the call against the 256 MiB Infinity Cache: larger ones stream (non-temporal policy, aux_kernels.hpp)
+    constexpr size_t NARR = OP == PW_NORMALIZE ? 1 : OP == PW_MUL_ACCUMULATE ? 3 : 2;
+    if (NARR * count * sizeof(T) > ((size_t)384 << 20))
+        hipLaunchKernelGGL((pointwise_kernel<T, OP, true>), dim3(ew_grid(nv)), dim3(256), 0, st, a, b, c, pl->mp, count);
+    else
+        hipLaunchKernelGGL((pointwise_kernel<T, OP, false>), dim3(ew_grid(nv)), dim3(256), 0, st, a, b, c, pl->mp, count);
     HIP_TRY(hipGetLastError());
     return CNTT_OK;
 }

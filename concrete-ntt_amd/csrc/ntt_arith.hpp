@@ -65,6 +65,9 @@ template <class T> struct ModParams {
     // product between the transforms is a Montgomery product there (mul_fused) and leaves a factor 2^-B for the last inverse stage
     T mont_n_inv, mont_n_inv_shoup, mont_last_w, mont_last_w_shoup;
     T mont_r, mont_r_shoup;   // 2^B mod p and its Shoup companion: the fused mul_accumulate chains undo their products' 2^-B with it
+    // set per LAUNCH by the host (0 in the plan): the batch of this call is larger than the 256 MiB Infinity Cache and passes through the
+    // chip once -- the stand-alone transform kernels then put the non-temporal hint on their tile loads and stores (ntt_kernel.hpp)
+    uint32_t stream;
 };
 
 // ---------------------------------------------------------------------------------------------

@@ -63,17 +63,26 @@ struct NttBlk {
         static constexpr bool B16 = NV * sizeof(T) == 16;   // 16-byte loads (8-byte ones otherwise)
         static_assert(NV * sizeof(T) == 16 || NV * sizeof(T) == 8, "prefetch vectors of 8 or 16 bytes");
         using V = typename std::conditional<B16, Vec4, Vec2>::type;
-        template <int JV = 0> static __device__ __forceinline__ void issue(V (&v)[NVEC], const T *tile, uint32_t voff) {
+        template <int JV = 0, bool NT = false> static __device__ __forceinline__ void issue(V (&v)[NVEC], const T *tile, uint32_t voff) {
             if constexpr (JV < NVEC) {
                 constexpr uint32_t BYTE = cdep((uint32_t)(JV * NV), RM) * (uint32_t)sizeof(T);
                 constexpr uint32_t WIN = BYTE & ~4095u, IMM = BYTE & 4095u;
                 const char *base = reinterpret_cast<const char *>(tile) + WIN;
-                if constexpr (B16)
+                if constexpr (B16 && NT)
                     asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3 nt" : "=v"(v[JV]) : "v"(voff), "s"(base), "n"(IMM) : "memory");
-                else
+                else if constexpr (B16)
+                    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(v[JV]) : "v"(voff), "s"(base), "n"(IMM) : "memory");
+                else if constexpr (NT)
                     asm volatile("global_load_dwordx2 %0, %1, %2 offset:%3 nt" : "=v"(v[JV]) : "v"(voff), "s"(base), "n"(IMM) : "memory");
-                issue<JV + 1>(v, tile, voff);
+                else
+                    asm volatile("global_load_dwordx2 %0, %1, %2 offset:%3" : "=v"(v[JV]) : "v"(voff), "s"(base), "n"(IMM) : "memory");
+                issue<JV + 1, NT>(v, tile, voff);
             }
+        }
+        // policy chosen at run time (ModParams::stream; NttKernel::gather_async_rt)
+        static __device__ __forceinline__ void issue_rt(V (&v)[NVEC], const T *tile, uint32_t voff, bool nt) {
+            if (nt) issue<0, true>(v, tile, voff);
+            else issue<0, false>(v, tile, voff);
         }
         // every destination vector is a tied operand of the ONE waiting statement
         template <int YOUNGER> static __device__ __forceinline__ void wait(V (&v)[NVEC]) {
@@ -168,6 +177,7 @@ struct NttBlk {
         constexpr uint32_t CML = FULL & ~LOAD_RM, CMS = FULL & ~STORE_RM;
         constexpr int NST = E / nv<STORE_RM>();  // store instructions per polynomial (younger than the prefetch)
         const uint32_t tid = threadIdx.x;
+        const bool nt = P.stream != 0;   // the batch streams: non-temporal tile loads and stores (NttKernel::scatter_tile)
         T r[E];
 #pragma unroll
         for (int j = 0; j < E; ++j) r[j] = 0;
@@ -179,7 +189,7 @@ struct NttBlk {
         if constexpr (PREFETCH) {
             if (tile < nsub) {
                 typename PF::V v0[PF::NVEC];
-                PF::issue(v0, (const T *)(data + ((size_t)tile << LOGN)), pdep<CML>(tid) * (uint32_t)sizeof(T));
+                PF::issue_rt(v0, (const T *)(data + ((size_t)tile << LOGN)), pdep<CML>(tid) * (uint32_t)sizeof(T), nt);
                 PF::template wait<0>(v0);
                 PF::unpack(r, v0);
             }
@@ -195,7 +205,7 @@ struct NttBlk {
             typename PF::V vn[PF::NVEC];
             auto prefetch = [&]() {
                 if constexpr (PREFETCH) {
-                    if (more) PF::issue(vn, (const T *)(data + ((size_t)tnext << LOGN)), pdep<CML>(tidv) * (uint32_t)sizeof(T));
+                    if (more) PF::issue_rt(vn, (const T *)(data + ((size_t)tnext << LOGN)), pdep<CML>(tidv) * (uint32_t)sizeof(T), nt);
                 }
             };
             if constexpr (!PREFETCH) B::template gather_tile<LOAD_RM>(r, (const T *)tbase, pdep<CML>(tidv) * (uint32_t)sizeof(T));
@@ -222,7 +232,7 @@ struct NttBlk {
 #pragma unroll
                 for (int j = 0; j < E; ++j) r[j] = Bfly<T, CLS>::finish_inv(r[j], P);
             }
-            B::template scatter_tile<STORE_RM>(r, tbase, pdep<CMS>(tidv) * (uint32_t)sizeof(T));
+            B::template scatter_tile_rt<STORE_RM>(r, tbase, pdep<CMS>(tidv) * (uint32_t)sizeof(T), nt);
             if constexpr (PREFETCH) {
                 if (more) {
                     PF::template wait<NST>(vn);

@@ -161,9 +161,11 @@ struct NttKernel {
     }
 
     // ---- tile-relative global addressing (persistent kernels) -----------------------------------
-    // Batch data streams through the chip exactly once per launch: every tile load and store carries the non-temporal hint (round 5:
-    // loads AND stores together -3 % on the N = 1024 transforms, either alone nothing -- profiles/r05_nt_hint_ab.txt; the plan tables keep
-    // the default policy, they are what L2 should hold).
+    // NT (round 5): the non-temporal hint for batches that stream through the chip once (larger than the 256 MiB Infinity Cache:
+    // ModParams::stream, decided per launch by the host).  On the asynchronous tile loads AND the tile stores of the stand-alone
+    // transforms together it is worth -3 % (either alone nothing; nothing in the fused product, whose rhs loads are synchronous and get
+    // slower with it: profiles/r05_nt_hint_ab.txt, r05_nt_headline_ab.txt); on a batch that fits the cache it costs 3 ... 6 %, because the
+    // next kernel then finds nothing there (profiles/r05_small_batch_ab.txt).  The plan tables always keep the default policy.
     // A tile's address is a workgroup-uniform base (an SGPR pair) plus ONE 32-bit byte offset per thread: the
     // compiler selects global_load / global_store with an saddr operand, and no 64-bit per-thread pointers live in
     // VGPRs across the butterflies.
@@ -199,21 +201,28 @@ struct NttKernel {
             }
         }
     }
-    template <uint32_t RM> static __device__ __forceinline__ void scatter_tile(const T (&r)[E], T *tile, uint32_t voff) {
+    template <uint32_t RM, bool NT = false> static __device__ __forceinline__ void scatter_tile(const T (&r)[E], T *tile, uint32_t voff) {
         constexpr int NV = vec_elems<RM>();
         using V = typename VecOf<T, NV>::type;
 #pragma unroll
         for (int j = 0; j < E; j += NV) {
             const uint32_t off = voff + cdep((uint32_t)j, RM) * (uint32_t)sizeof(T);
             if constexpr (NV == 1) {
-                __builtin_nontemporal_store(r[j], reinterpret_cast<T *>(reinterpret_cast<char *>(tile) + off));
+                if constexpr (NT) __builtin_nontemporal_store(r[j], reinterpret_cast<T *>(reinterpret_cast<char *>(tile) + off));
+                else *reinterpret_cast<T *>(reinterpret_cast<char *>(tile) + off) = r[j];
             } else {
                 V v;
 #pragma unroll
                 for (int i = 0; i < NV; ++i) v[i] = r[j + i];
-                __builtin_nontemporal_store(v, reinterpret_cast<V *>(reinterpret_cast<char *>(tile) + off));
+                if constexpr (NT) __builtin_nontemporal_store(v, reinterpret_cast<V *>(reinterpret_cast<char *>(tile) + off));
+                else *reinterpret_cast<V *>(reinterpret_cast<char *>(tile) + off) = v;
             }
         }
+    }
+    // the same with the policy chosen at run time (a workgroup-uniform flag: one scalar branch around the tile's stores)
+    template <uint32_t RM> static __device__ __forceinline__ void scatter_tile_rt(const T (&r)[E], T *tile, uint32_t voff, bool nt) {
+        if (nt) scatter_tile<RM, true>(r, tile, voff);
+        else scatter_tile<RM, false>(r, tile, voff);
     }
 
     // ---- software-pipelined global loads (persistent kernel) ------------------------------------
@@ -229,7 +238,7 @@ struct NttKernel {
 
     // The loads use the saddr form (SGPR-pair base + 32-bit VGPR byte offset + 13-bit immediate): the per-vector
     // element offsets cdep(j, RM) are compile-time constants.
-    template <uint32_t RM, int JV = 0>
+    template <uint32_t RM, int JV = 0, bool NT = false>
     static __device__ __forceinline__ void gather_async(AsyncVec (&v)[E / MAXV], const T *tile, uint32_t voff) {
         if constexpr (JV < E / MAXV) {
             // the 4 KiB window of a vector goes into the scalar base (SALU add), the rest into the immediate: one VGPR
@@ -237,9 +246,15 @@ struct NttKernel {
             constexpr uint32_t BYTE = cdep((uint32_t)(JV * MAXV), RM) * (uint32_t)sizeof(T);
             constexpr uint32_t WIN = BYTE & ~4095u, IMM = BYTE & 4095u;
             const char *base = reinterpret_cast<const char *>(tile) + WIN;
-            asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3 nt" : "=v"(v[JV]) : "v"(voff), "s"(base), "n"(IMM) : "memory");
-            gather_async<RM, JV + 1>(v, tile, voff);
+            if constexpr (NT) asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3 nt" : "=v"(v[JV]) : "v"(voff), "s"(base), "n"(IMM) : "memory");
+            else asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(v[JV]) : "v"(voff), "s"(base), "n"(IMM) : "memory");
+            gather_async<RM, JV + 1, NT>(v, tile, voff);
         }
+    }
+    template <uint32_t RM>
+    static __device__ __forceinline__ void gather_async_rt(AsyncVec (&v)[E / MAXV], const T *tile, uint32_t voff, bool nt) {
+        if (nt) gather_async<RM, 0, true>(v, tile, voff);
+        else gather_async<RM, 0, false>(v, tile, voff);
     }
     // wait until at most YOUNGER vector-memory operations (issued after the async loads) are outstanding
     template <int YOUNGER> static __device__ __forceinline__ void wait_async(AsyncVec (&v)[E / MAXV]) {
@@ -648,6 +663,7 @@ struct NttWp : NttKernel<T, LOGN, INV, CLS, false, FAM> {
         }
         const uint32_t tid = threadIdx.x & (TPP - 1);
         const uint32_t pl = threadIdx.x / TPP;
+        const bool nt = P.stream != 0;   // workgroup-uniform: the batch streams (see gather_tile / NT above)
         T *lds = lds_all + (size_t)pl * B::LDS_WORDS_1;
         constexpr uint32_t RM0 = S::RMASK[0], CM0 = FULL & ~RM0;
         constexpr uint32_t RML = S::RMASK[NPASS - 1], CML = FULL & ~RML;
@@ -668,8 +684,8 @@ struct NttWp : NttKernel<T, LOGN, INV, CLS, false, FAM> {
             const uint32_t last = nsub - 1u - tile * PPB;   // ragged tail: clamp to the last polynomial (in range)
             const uint32_t pl0 = pl < last ? pl : last;
             typename B::AsyncVec v0[E / B::MAXV];
-            B::template gather_async<IO_RM>(v0, (const T *)(data + (((size_t)tile * PPB) << LOGN)),
-                                            ((pl0 << LOGN) + ebaseIO) * (uint32_t)sizeof(T));
+            B::template gather_async_rt<IO_RM>(v0, (const T *)(data + (((size_t)tile * PPB) << LOGN)),
+                                               ((pl0 << LOGN) + ebaseIO) * (uint32_t)sizeof(T), nt);
             B::template wait_async<0>(v0);
             B::unpack_async(r, v0);
         }
@@ -693,8 +709,8 @@ struct NttWp : NttKernel<T, LOGN, INV, CLS, false, FAM> {
                 // ragged tail: lanes of polynomials past the end re-read the last polynomial (harmless, in range)
                 const uint32_t last = nsub - 1u - tnext * PPB;
                 const uint32_t pln = pl < last ? pl : last;
-                B::template gather_async<IO_RM>(vn, (const T *)(data + (((size_t)tnext * PPB) << LOGN)),
-                                                ((pln << LOGN) + ebIO) * (uint32_t)sizeof(T));
+                B::template gather_async_rt<IO_RM>(vn, (const T *)(data + (((size_t)tnext * PPB) << LOGN)),
+                                                   ((pln << LOGN) + ebIO) * (uint32_t)sizeof(T), nt);
             }
 #pragma unroll
             for (int j = 0; j < E; ++j) r[j] = Bfly<T, CLS>::load_fix(r[j], P);  // memory word -> register form
@@ -711,7 +727,7 @@ struct NttWp : NttKernel<T, LOGN, INV, CLS, false, FAM> {
                 wsync();
                 B::template gather<IO_RM>(r, (const T *)lds, ebIO, true);
             }
-            if (sub < nsub) B::template scatter_tile<IO_RM>(r, tbase, voff);
+            if (sub < nsub) B::template scatter_tile_rt<IO_RM>(r, tbase, voff, nt);
             wsync();  // the exchange buffer is reused by the next tile
             if (more) {
                 // lanes of inactive polynomials skipped their stores: the counter then allows fewer
