@@ -64,8 +64,8 @@ namespace {
 struct SwitchDef { const char *name; int dflt; };
 constexpr SwitchDef kSwitches[DBG_COUNT] = {
     {"fp", 1}, {"pm64", 1}, {"blk", 1}, {"mul32_blk", 1}, {"ext32_blk", 1}, {"ext_one", 1}, {"ext_split", -1}, {"native_acc", 1},
-    {"product_fused", -1}};
-std::atomic<int> g_switch[DBG_COUNT] = {{1}, {1}, {1}, {1}, {1}, {1}, {-1}, {1}, {-1}};
+    {"product_fused", -1}, {"plan52_via32", 1}};
+std::atomic<int> g_switch[DBG_COUNT] = {{1}, {1}, {1}, {1}, {1}, {1}, {-1}, {1}, {-1}, {1}};
 int switch_index(const char *key) {
     if (!key) return -1;
     for (int i = 0; i < (int)DBG_COUNT; ++i)
@@ -806,6 +806,11 @@ struct cntt_native {
     AccArgs acc{};
     ModParams<uint32_t> mp_acc[10];
     bool has_acc = false;
+    // Plan52 kinds (round 5): negacyclic_polymul returns the wrapping image of the EXACT integer product, which does not depend on the
+    // primes it was computed with (native_fused.hpp, accumulating CRT) -- so it runs the whole-product kernel of the Plan32 kind with the
+    // same words (30-bit primes: the faster arithmetic on this chip; the reference offers Plan52 for AVX-512 IFMA hosts).  fwd / inv of
+    // the plan, whose 50-bit residues are visible, stay on its own primes.  Absent where the Plan32 kind does not exist (n < 32).
+    std::unique_ptr<cntt_native> via32;
     std::shared_ptr<NativeCache> cache;
     size_t rbytes() const { return info.is52 ? 8 : 4; }
     uint64_t prime(int i) const { return info.is52 ? PRIMES52[i] : (uint64_t)PRIMES32[i]; }
@@ -924,6 +929,14 @@ extern "C" int cntt_native_plan_new(cntt_native_kind_t kind, size_t n, cntt_nati
     build_crt_args(pl.get());
     build_acc_args(pl.get());
     pl->cache = std::make_shared<NativeCache>();
+    if (pl->info.is52) {
+        static const cntt_native_kind_t SAME_WORDS[10] = {CNTT_NATIVE32_PLAN32, CNTT_NATIVE64_PLAN32, CNTT_NATIVE128_PLAN32,
+                                                          CNTT_NATIVE_BINARY32_PLAN32, CNTT_NATIVE_BINARY64_PLAN32,
+                                                          CNTT_NATIVE_BINARY128_PLAN32, CNTT_NATIVE32_PLAN32, CNTT_NATIVE64_PLAN32,
+                                                          CNTT_NATIVE_BINARY32_PLAN32, CNTT_NATIVE_BINARY64_PLAN32};
+        cntt_native_t *v = nullptr;
+        if (cntt_native_plan_new(SAME_WORDS[kind], n, &v) == CNTT_OK) pl->via32.reset(v);   // None (n < 32 ...): composed path
+    }
     *out = pl.release();
     return CNTT_OK;
 }
@@ -1125,6 +1138,13 @@ static size_t native_workspace_bytes(const cntt_native *pl, size_t batch) {
     if (native_fusable(pl, batch) && pl->p32[0]->logn >= 5 && pl->p32[0]->logn <= 12 && pl->kind != CNTT_NATIVE128_PLAN32) return 0;
     return 2 * (size_t)pl->info.nprimes * batch * pl->n * pl->rbytes();
 }
+// Plan52 kinds: does negacyclic_polymul run the Plan32 whole-product kernel of the same words?  (Measured, ns per product, through it /
+// composed on the 50-bit primes, profiles/r05_plan52_via32.txt: native64 n = 4096 102 / 187, native32 n = 1024 12 / 28.5,
+// native_binary64 n = 16384 384 / 572 ...; the one shape where the composed pipeline wins is native64 at n = 32768: 1816 / 1769.)
+static bool plan52_via32(const cntt_native *pl) {
+    if (!pl->via32 || debug_switch(DBG_PLAN52_VIA32) == 0) return false;
+    return !(pl->kind == CNTT_NATIVE64_PLAN52 && pl->n >= 32768);
+}
 // caller holds pl->cache->mu
 static int native_workspace(const cntt_native *pl, size_t need, Workspace **out) {
     int dev = 0;
@@ -1148,6 +1168,7 @@ static int native_workspace(const cntt_native *pl, size_t need, Workspace **out)
 }
 extern "C" int cntt_native_reserve(const cntt_native_t *pl, size_t batch) {
     if (!pl) return fail(CNTT_EINVAL, "plan is NULL");
+    if (plan52_via32(pl)) return cntt_native_reserve(pl->via32.get(), batch);
     std::lock_guard<std::mutex> lk(pl->cache->mu);
     Workspace *w = nullptr;
     return native_workspace(pl, native_workspace_bytes(pl, batch), &w);
@@ -1199,6 +1220,7 @@ static int native_fused_device(const cntt_native *pl, void *prod, const void *lh
 
 static int native_polymul_device(const cntt_native *pl, void *prod, const void *lhs, const void *rhs, size_t batch,
                                  hipStream_t st) {
+    if (plan52_via32(pl)) return native_polymul_device(pl->via32.get(), prod, lhs, rhs, batch, st);
     const size_t park = native_park_bytes(pl, batch);
     if (park == 0 && native_fusable(pl, batch)) {
         const int rc = native_fused_device(pl, prod, lhs, rhs, batch, nullptr, st);

@@ -20,6 +20,7 @@ enum DebugSwitch : int {
     DBG_EXT_SPLIT,      // -1 (default): split launches of 3 / 4 outputs where they measured faster; 0 never; 1 always
     DBG_NATIVE_ACC,     // 1 (default): accumulating-CRT whole-product kernels; 0: the parked-tile kernels
     DBG_PRODUCT_FUSED,  // -1 (default): product::Plan composed forward, fused inverse; 0 neither fused; 1 both fused
+    DBG_PLAN52_VIA32,   // 1 (default): negacyclic_polymul of the Plan52 native kinds runs the Plan32 whole-product kernel; 0: composed on 50-bit primes
     DBG_COUNT
 };
 int debug_switch(DebugSwitch key);

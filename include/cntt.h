@@ -92,6 +92,7 @@ int cntt_shard_bounds(size_t batch, int world, int rank, size_t *begin, size_t *
 /*   "ext_split"        -1     split launches for 3 / 4 outputs where measured faster; 0 never; 1 always                              */
 /*   "native_acc"        1     accumulating-CRT whole-product kernels; 0: the parked-tile kernels                                     */
 /*   "product_fused"    -1     product::Plan: composed forward + fused inverse; 0 neither fused; 1 both                               */
+/*   "plan52_via32"      1     negacyclic_polymul of the Plan52 native kinds through the Plan32 whole-product kernel; 0: 50-bit primes */
 /* value -1 restores a switch's default; key "reset" restores all.  Process-wide, thread-safe (atomics); the two class switches are    */
 /* recorded in the plan at creation (cntt_prime*_plan_info().arith_class reports the class in use), the others are read per call.      */
 /* ------------------------------------------------------------------------------------- */
@@ -218,8 +219,9 @@ int cntt_native_inv_batch(const cntt_native_t *plan, void *value, void *const *r
 /* The device path of the Plan32 kinds is one kernel for 32 <= n <= 32768.  n <= 4096 (except native128) needs no
  * workspace (nor n = 8192 of native32 / native64 / native_binary64); the other n = 8192 kinds, n = 16384 / 32768 and native128 park
  * residue tiles in a per-plan, per-device workspace of a few tens of MiB (n = 32768: 64 ... 300 MiB, native128 the most),
- * independent of the batch; the Plan52 kinds run the composed pipeline on a workspace of
- * 2 * nprimes * batch * n residues.  The workspace grows on demand (an allocation, and a device synchronisation when it
+ * independent of the batch; the Plan52 kinds (round 5) run the whole-product kernel of the Plan32 kind with the same words -- the
+ * wrapping product does not depend on the primes it is computed with -- and fall back to the composed pipeline on a workspace of
+ * 2 * nprimes * batch * n residues where that kind does not exist (n < 32) or when the testing switch "plan52_via32" is 0.  The workspace grows on demand (an allocation, and a device synchronisation when it
  * is replaced): reserve it ahead of a timed or captured region with cntt_native_reserve().  Calls on different streams
  * that share a plan are ordered against each other by the library wherever they share the workspace -- EXCEPT while a
  * stream is being captured into a hipGraph: a captured launch neither waits on nor records the workspace event, and it

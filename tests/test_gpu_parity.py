@@ -773,6 +773,36 @@ def test_c3_c5_native_full_n(oracle):
         assert np.array_equal(to_host(dp, np.uint64), want), kind
 
 
+@pytest.mark.parametrize("kind", ["native32_plan52", "native64_plan52", "native_binary32_plan52", "native_binary64_plan52"])
+def test_plan52_polymul_through_the_plan32_kernel_equals_the_50_bit_pipeline(oracle, kind):
+    """Round 5: negacyclic_polymul of a Plan52 kind runs the Plan32 whole-product kernel of the same words (the wrapping product does not
+    depend on the primes: src/native64.rs:1074-1165 against :1042-1069 return the same words).  Here: that path == the composed pipeline on
+    the 50-bit primes (testing switch plan52_via32 = 0) == the oracle's Plan52, for sizes on both sides of every kernel shape, extremes
+    included; n = 16 (no Plan32 plan exists there: prime32 needs n >= 32) takes the composed path by itself."""
+    torch = _torch()
+    cls = NATIVE[kind]
+    for n in (16, 32, 1024, 4096, 8192, 32768):
+        plan = cls.try_new(n)
+        ref, lhs, rhs = _native_inputs(oracle, kind, n, 777 + n, cls.BINARY)
+        batch = 5
+        lhs = np.concatenate([lhs] * batch)
+        rhs = np.concatenate([rhs] * batch)
+        lhs[:n] = np.iinfo(lhs.dtype).max                      # one all-ones product: the bound of |c|
+        if not cls.BINARY:
+            rhs[:n] = np.iinfo(rhs.dtype).max
+        want = np.zeros_like(lhs)
+        ref.negacyclic_polymul_batch(want, lhs, rhs, batch, 4)
+        sdt = np.int64 if lhs.dtype == np.uint64 else np.int32
+        outs = []
+        for via in (1, 0):
+            with cntt.debug_switches(plan52_via32=via):
+                dp = torch.zeros(lhs.size, dtype=torch.int64 if sdt == np.int64 else torch.int32, device="cuda")
+                plan.negacyclic_polymul_batch(dp, torch.from_numpy(lhs.view(sdt)).cuda(), torch.from_numpy(rhs.view(sdt)).cuda())
+                outs.append(dp.cpu().numpy().view(lhs.dtype))
+        assert np.array_equal(outs[0], want), (kind, n, "through the Plan32 kernel")
+        assert np.array_equal(outs[1], want), (kind, n, "composed on the 50-bit primes")
+
+
 def _composed_polymul(torch, plan, cls, dl, dr, batch, n):
     """split -> per-prime transforms -> pointwise -> inverse -> CRT through the plan's separate entry points"""
     rl = [torch.empty(batch * n, dtype=torch.int32, device="cuda") for _ in range(cls.NPRIMES)]

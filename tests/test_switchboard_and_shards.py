@@ -14,7 +14,7 @@ from concrete_ntt_amd import shard
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SWITCHES = {"fp": 1, "pm64": 1, "blk": 1, "mul32_blk": 1, "ext32_blk": 1, "ext_one": 1, "ext_split": -1, "native_acc": 1,
-            "product_fused": -1}
+            "product_fused": -1, "plan52_via32": 1}
 
 
 def test_switchboard_defaults_set_get_reset():

@@ -15,13 +15,16 @@ from concrete_ntt_amd import native32, native64, native128, native_binary32, nat
 
 KINDS = {"native32": (native32.Plan32, 4), "native64": (native64.Plan32, 8), "native128": (native128.Plan32, 16),
          "native_binary32": (native_binary32.Plan32, 4), "native_binary64": (native_binary64.Plan32, 8),
-         "native_binary128": (native_binary128.Plan32, 16)}
+         "native_binary128": (native_binary128.Plan32, 16),
+         "native32_52": (native32.Plan52, 4), "native64_52": (native64.Plan52, 8),
+         "native_binary32_52": (native_binary32.Plan52, 4), "native_binary64_52": (native_binary64.Plan52, 8)}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("kinds", nargs="*", default=["native128", "native_binary128"])
     ap.add_argument("--n", default="4096,8192,16384")
+    ap.add_argument("--switch", default="native_acc", help="testing-only switch to toggle (1 = first column, 0 = second): native_acc, plan52_via32")
     ap.add_argument("--tag", default="")   # tools/ab_lib.sh appends --tag new|old
     args = ap.parse_args()
     for kind in args.kinds:
@@ -40,7 +43,7 @@ def main():
                     rhs.view(-1, 2)[:, 1] = 0
             res = {}
             for acc in (1, 0, 1, 0):
-                with cntt.debug_switches(native_acc=acc):
+                with cntt.debug_switches(**{args.switch: acc}):
                     plan = cls.try_new(n)
                     plan.reserve(batch)
                     out = torch.empty_like(lhs)
@@ -58,8 +61,8 @@ def main():
                     res.setdefault(acc, []).append((ns, out.clone()))
             same = torch.equal(res[1][0][1], res[0][0][1])
             by = 3 * n * word
-            print(args.tag, "%-18s n=%6d  acc %8.1f / %8.1f ns (%4.1f %%)   parked %8.1f / %8.1f ns (%4.1f %%)   identical=%s" % (
-                kind, n, res[1][0][0], res[1][1][0], 100 * by / min(r[0] for r in res[1]) / 8000.0,
+            print(args.tag, "%-18s n=%6d  " % (kind, n) + args.switch + "=1 %8.1f / %8.1f ns (%4.1f %%)   =0 %8.1f / %8.1f ns (%4.1f %%)   identical=%s" % (
+                res[1][0][0], res[1][1][0], 100 * by / min(r[0] for r in res[1]) / 8000.0,
                 res[0][0][0], res[0][1][0], 100 * by / min(r[0] for r in res[0]) / 8000.0, same), flush=True)
             del lhs, rhs, res
             torch.cuda.empty_cache()
