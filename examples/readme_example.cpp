@@ -40,6 +40,9 @@ int main() {
         pplan.inv(round, ntt, cntt::product::InvMode::Replace);
         for (size_t i = 0; i < m; ++i)
             if (round[i] != (uint64_t)((u128)standard[i] * m % (p0 * p1))) return std::puts("MISMATCH product"), 2;
+        // host-only helpers of the mirror: the batch partition for multi-device callers and the testing-only switchboard
+        const auto sh = cntt::shard_bounds(10, 3, 2);   // 10 polynomials over 3 devices: [0,4) [4,7) [7,10)
+        if (sh.first != 7 || sh.second != 10 || cntt::debug_get("native_acc") != 1) return std::puts("MISMATCH helpers"), 2;
         std::puts("Success!");
         return 0;
     } catch (const cntt::DeviceError &e) {

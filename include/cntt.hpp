@@ -48,6 +48,21 @@ template <class H, class F> std::optional<H *> try_handle(F &&make) {
     return h;
 }
 
+// Contiguous shard [begin, end) of `rank` when a batch of independent polynomials is split over `world` devices (cntt_shard_bounds;
+// SURVEY 8e): the caller drives the devices -- one thread + stream per device around a shared plan, examples/multi_device.cpp.
+inline std::pair<size_t, size_t> shard_bounds(size_t batch, int world, int rank) {
+    size_t b = 0, e = 0;
+    check(cntt_shard_bounds(batch, world, rank, &b, &e));
+    return {b, e};
+}
+// TESTING ONLY (include/cntt.h): kernel-selection switches for A/B timing and device-vs-device parity tests; results never change.
+inline void debug_set(const char *key, int value) { check(cntt_debug_set(key, value)); }
+inline int debug_get(const char *key) {
+    int v = 0;
+    check(cntt_debug_get(key, &v));
+    return v;
+}
+
 template <class T> struct PrimeApi;
 #define CNTT_PRIME_TRAITS(BITS, T)                                                                                   \
     template <> struct PrimeApi<T> {                                                                                 \
