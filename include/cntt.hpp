@@ -48,21 +48,6 @@ template <class H, class F> std::optional<H *> try_handle(F &&make) {
     return h;
 }
 
-// Contiguous shard [begin, end) of `rank` when a batch of independent polynomials is split over `world` devices (cntt_shard_bounds;
-// SURVEY 8e): the caller drives the devices -- one thread + stream per device around a shared plan, examples/multi_device.cpp.
-inline std::pair<size_t, size_t> shard_bounds(size_t batch, int world, int rank) {
-    size_t b = 0, e = 0;
-    check(cntt_shard_bounds(batch, world, rank, &b, &e));
-    return {b, e};
-}
-// TESTING ONLY (include/cntt.h): kernel-selection switches for A/B timing and device-vs-device parity tests; results never change.
-inline void debug_set(const char *key, int value) { check(cntt_debug_set(key, value)); }
-inline int debug_get(const char *key) {
-    int v = 0;
-    check(cntt_debug_get(key, &v));
-    return v;
-}
-
 template <class T> struct PrimeApi;
 #define CNTT_PRIME_TRAITS(BITS, T)                                                                                   \
     template <> struct PrimeApi<T> {                                                                                 \
@@ -208,6 +193,22 @@ template <cntt_native_kind_t KIND, class R, int NPRIMES, int WORD_BYTES> class N
     void reserve(size_t batch) const { check(cntt_native_reserve(h_, batch)); }
 };
 }  // namespace detail
+
+// Contiguous shard [begin, end) of `rank` when a batch of independent polynomials is split over `world` devices (cntt_shard_bounds;
+// SURVEY 8e): the caller drives the devices -- one thread + stream per device around a shared plan, examples/multi_device.cpp.
+inline std::pair<size_t, size_t> shard_bounds(size_t batch, int world, int rank) {
+    size_t b = 0, e = 0;
+    detail::check(cntt_shard_bounds(batch, world, rank, &b, &e));
+    return {b, e};
+}
+// TESTING ONLY (include/cntt.h): kernel-selection switches for A/B timing and device-vs-device parity tests; results never change.
+inline void debug_set(const char *key, int value) { detail::check(cntt_debug_set(key, value)); }
+inline int debug_get(const char *key) {
+    int v = 0;
+    detail::check(cntt_debug_get(key, &v));
+    return v;
+}
+
 
 namespace prime32 {
 using Plan = detail::PrimePlan<uint32_t>;
