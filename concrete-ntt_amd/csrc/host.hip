@@ -507,7 +507,7 @@ template <class T> static int mul_ntt_device(const PrimePlan<T> *pl, T *lhs, con
 //                   62-bit  1.74 / 1.61, 1.98 / 1.88     63-bit  1.87 / 1.70, 2.16 / 1.99                     -> composed
 //   u32 n = 32768   30-bit  1.45 / 1.61, 1.73 / 1.94                                                          -> split
 //                   31-bit  1.70 / 1.75, 2.01 / 1.97     p >= 2^31 (doubles)  2.14 / 2.07, 2.58 / 2.48        -> composed
-// CNTT_EXT_SPLIT=0 never splits, =1 always does (A/B runs); the decision of the call in flight sits in a thread-local because
+// cntt_debug_set("ext_split", 0) never splits, 1 always does (A/B runs); the decision of the call in flight sits in a thread-local because
 // launch_ext_ntt() (ntt_launch.hpp) only asks ext_split_enabled().
 static thread_local bool g_ext_split_wins = true;
 static bool ext_split_wins(size_t word, int logn, int cls) {

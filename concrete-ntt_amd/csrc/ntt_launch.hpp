@@ -110,7 +110,7 @@ hipError_t launch_product_fused2(int logn, int cls, bool inv, uint64_t *standard
 // kind 2 at every size) parks residue
 // tiles in `scratch` (native_fused_scratch_words() 32-bit words); the other shapes ignore it.
 // `acc` (round 4): constants of the accumulating CRT and `tables_acc`, the FusedTables whose last-stage constants carry
-// (M / P_i)^-1 / n -- the sizes that have the register-resident kernel (native_fused_acc()) run it unless CNTT_NATIVE_ACC=0.
+// (M / P_i)^-1 / n -- the sizes that have the register-resident kernel (native_fused_acc()) run it unless the testing switch native_acc is 0.
 template <int KIND>
 hipError_t launch_native_fused(int logn, void *prod, const void *lhs, const void *rhs, const void *tables, const SplitArgs &S,
                                const CrtArgs &C, uint32_t batch, uint32_t *scratch, hipStream_t st, const AccArgs *acc,

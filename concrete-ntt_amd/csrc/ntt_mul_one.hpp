@@ -73,7 +73,7 @@ static hipError_t mul_blk_one(T *lhs, const T *rhs, const TwPair<T> *twf, const 
 
 // 32-bit words, N = 16384 / 32768 on the same walk (2048-word blocks, 32 coefficients per thread; two 512-thread / one 1024-thread workgroup per CU)
 // where it beats the one-polynomial-per-workgroup kernel (MulOne); ordinary loads except for the one shape with the registers to spare (an
-// asynchronous load must not meet a spilled register).  Same box, ns per product, walk / MulOne (tools/mul_bench.py, CNTT_MUL32_BLK=0 for the latter):
+// asynchronous load must not meet a spilled register).  Same box, ns per product, walk / MulOne (tools/mul_bench.py, testing switch mul32_blk = 0 for the latter):
 //   30-bit  n = 16384  71.3 / 73.8 (-3.4 %, with the prefetch; -1.7 % without)   n = 32768  156.5 / 173.5 (-9.8 %)
 //   31-bit  n = 16384  81.5 / 75.4 (+8.1 %: not used)                             n = 32768  176.5 / 195.7 (-9.8 %)
 //   p>=2^31 n = 16384  95.2 / 101.4 (-6.2 %)                                      n = 32768  216.2 / 204.1 (+5.9 %, 17 spilled registers: not used)
